@@ -1,0 +1,508 @@
+// gf_capi.hip -- host side of the C ABI declared in include/golemflavor_hip.h.
+// Owns: descriptor validation, derivation of the per-run constants, device/stream/staging-buffer
+// management and the launch calls.  There is deliberately no CPU evaluation path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/golemflavor_hip.h"
+#include "gf_consts.h"
+#include "gf_launch.h"
+
+static_assert(GF_MAX_DIM == 16 && GF_MAX_BINS == 64, "header / device constant mismatch");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int hip_fail(hipError_t e, const char* what)
+{
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return GF_ERR_HIP;
+}
+
+#define GF_HIP(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+typedef long double ld;
+typedef std::complex<long double> cld;
+
+// golemflavor/fr.py:116-162 in the algebraic form, long double, host side only:
+// used once per model for the fixed-texture projectors.
+void mixing_matrix_ld(const double ang[4], cld u[3][3])
+{
+    const ld s12_2 = ang[0], c13_4 = ang[1], s23_2 = ang[2], dcp = ang[3];
+    const ld c13_2 = std::sqrt(c13_4);
+    const ld s12 = std::sqrt(s12_2), c12 = std::sqrt(1.0L - s12_2);
+    const ld c13 = std::sqrt(c13_2), s13 = std::sqrt(1.0L - c13_2);
+    const ld s23 = std::sqrt(s23_2), c23 = std::sqrt(1.0L - s23_2);
+    const cld ep(std::cos(dcp), std::sin(dcp)), em = std::conj(ep);
+    u[0][0] = c12 * c13;                       u[0][1] = s12 * c13;                       u[0][2] = s13 * em;
+    u[1][0] = -s12 * c23 - c12 * s23 * s13 * ep; u[1][1] = c12 * c23 - s12 * s23 * s13 * ep; u[1][2] = s23 * c13;
+    u[2][0] = s12 * s23 - c12 * c23 * s13 * ep;  u[2][1] = -c12 * s23 - s12 * c23 * s13 * ep; u[2][2] = c23 * c13;
+}
+
+bool finite_all(const double* p, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(p[i])) return false;
+    return true;
+}
+
+}  // namespace
+
+struct gf_model {
+    GfCommon c;
+    GfBsm hb;
+    GfBsm* d_bsm = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int cus = 256;
+    // staging for the host-buffer entry points (grown on demand, reused across calls)
+    int64_t cap = 0;
+    double* d_theta = nullptr;
+    double* d_out = nullptr;     // lnprob [cap] then fr [3 cap]
+    int32_t* d_status = nullptr;
+    void* h_pin = nullptr;       // pinned mirror: theta | lnprob | fr | status
+    size_t h_pin_bytes = 0;
+};
+
+namespace {
+
+int ensure_staging(gf_model* m, int64_t n)
+{
+    if (n <= m->cap) return GF_OK;
+    int64_t cap = m->cap ? m->cap : 1024;
+    while (cap < n) cap *= 2;
+    if (m->d_theta) (void)hipFree(m->d_theta);
+    if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_status) (void)hipFree(m->d_status);
+    if (m->h_pin) (void)hipHostFree(m->h_pin);
+    m->d_theta = nullptr; m->d_out = nullptr; m->d_status = nullptr; m->h_pin = nullptr; m->cap = 0;
+    const size_t nd = (size_t)m->c.ndim;
+    GF_HIP(hipMalloc((void**)&m->d_theta, sizeof(double) * nd * cap));
+    GF_HIP(hipMalloc((void**)&m->d_out, sizeof(double) * 4 * cap));
+    GF_HIP(hipMalloc((void**)&m->d_status, sizeof(int32_t) * cap));
+    m->h_pin_bytes = sizeof(double) * (nd + 4) * cap + sizeof(int32_t) * cap;
+    GF_HIP(hipHostMalloc(&m->h_pin, m->h_pin_bytes, hipHostMallocDefault));
+    m->cap = cap;
+    return GF_OK;
+}
+
+int check_dev_ptr(const void* p, size_t align)
+{
+    if (!p) return GF_ERR_INVALID_ARG;
+    if (((uintptr_t)p) % align) {
+        std::snprintf(g_err, sizeof(g_err), "device pointer %p is not %zu-byte aligned", p, align);
+        return GF_ERR_INVALID_ARG;
+    }
+    return GF_OK;
+}
+
+int launch_lnprob(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,
+                  int32_t* d_status)
+{
+    if (n == 0) return GF_OK;
+    hipError_t e;
+    if (m->c.mode == GF_MODE_BSM_GAUSS)
+        e = gf_launch_bsm(m->c, m->d_bsm, m->hb, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, m->stream);
+    else
+        e = gf_launch_lnprob_sm(m->c, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "lnprob launch");
+    return GF_OK;
+}
+
+int launch_propagate(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_fr, int32_t* d_status)
+{
+    if (n == 0) return GF_OK;
+    hipError_t e;
+    if (m->c.mode == GF_MODE_BSM_GAUSS)
+        e = gf_launch_bsm(m->c, m->d_bsm, m->hb, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, m->stream);
+    else
+        e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "propagate launch");
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gf_abi_version(void) { return GF_ABI_VERSION; }
+
+const char* gf_strerror(int err)
+{
+    switch (err) {
+    case GF_OK: return "ok";
+    case GF_ERR_INVALID_ARG: return "invalid argument";
+    case GF_ERR_NO_DEVICE: return "no gfx950 HIP device available (this library has no CPU fallback)";
+    case GF_ERR_HIP: return "HIP runtime error";
+    case GF_ERR_ALLOC: return "allocation failed";
+    case GF_ERR_COMM: return "RCCL error";
+    case GF_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+    }
+}
+
+const char* gf_last_hip_error(void) { return g_err; }
+
+int gf_device_count(int* count)
+{
+    if (!count) return GF_ERR_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return GF_OK; }
+    *count = n;
+    return GF_OK;
+}
+
+int gf_device_name(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return GF_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    GF_HIP(hipGetDeviceProperties(&prop, device));
+    std::snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return GF_OK;
+}
+
+int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
+{
+    if (!d || !out) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    g_err[0] = 0;
+    if (d->abi_version != GF_ABI_VERSION) {
+        std::snprintf(g_err, sizeof(g_err), "descriptor abi_version %d != library %d", d->abi_version, GF_ABI_VERSION);
+        return GF_ERR_INVALID_ARG;
+    }
+    if (d->ndim < 1 || d->ndim > GF_MAX_DIM) return GF_ERR_INVALID_ARG;
+    if (d->mode < GF_MODE_PRIOR_ONLY || d->mode > GF_MODE_BSM_GAUSS) return GF_ERR_INVALID_ARG;
+    auto idx_ok = [&](int i) { return i >= -1 && i < d->ndim; };
+    for (int k = 0; k < 4; ++k)
+        if (!idx_ok(d->idx_sm[k]) || !idx_ok(d->idx_mm[k])) return GF_ERR_INVALID_ARG;
+    for (int k = 0; k < 2; ++k)
+        if (!idx_ok(d->idx_mass[k]) || !idx_ok(d->idx_src[k])) return GF_ERR_INVALID_ARG;
+    if (!idx_ok(d->idx_scale) || !idx_ok(d->idx_gamma)) return GF_ERR_INVALID_ARG;
+    if ((d->idx_src[0] < 0) != (d->idx_src[1] < 0)) return GF_ERR_INVALID_ARG;
+
+    gf_model* m = new (std::nothrow) gf_model();
+    if (!m) return GF_ERR_ALLOC;
+    GfCommon& c = m->c;
+    std::memset(&c, 0, sizeof(c));
+    std::memset(&m->hb, 0, sizeof(m->hb));
+    c.ndim = d->ndim;
+    c.mode = d->mode;
+    for (int k = 0; k < 4; ++k) { c.idx_sm[k] = d->idx_sm[k]; c.idx_mm[k] = d->idx_mm[k]; c.sm_fixed[k] = d->sm_fixed[k]; c.mm_fixed[k] = d->mm_fixed[k]; }
+    for (int k = 0; k < 2; ++k) { c.idx_mass[k] = d->idx_mass[k]; c.idx_src[k] = d->idx_src[k]; c.mass_fixed[k] = d->mass_fixed[k]; }
+    c.idx_scale = d->idx_scale;
+    c.idx_gamma = d->idx_gamma;
+    c.scale_fixed = d->scale_fixed;
+
+    // priors: llh.py:81-90 + scipy truncnorm.logpdf = ((-z^2/2 - log sqrt(2pi)) - log_mass) - log(sigma)
+    const double logC = std::log(std::sqrt(2.0 * M_PI));
+    double pc = 0.0;
+    for (int i = 0; i < d->ndim; ++i) {
+        c.lo[i] = d->lo[i];
+        c.hi[i] = d->hi[i];
+        const int kind = d->prior_kind[i];
+        if (kind == GF_PRIOR_UNIFORM) {
+            c.loc[i] = 0.0;
+            c.inv_sigma[i] = 0.0;
+        } else if (kind == GF_PRIOR_GAUSSIAN || kind == GF_PRIOR_LIMITEDGAUSS) {
+            if (!(d->sigma[i] > 0.0) || !std::isfinite(d->loc[i]) || !std::isfinite(d->log_mass[i])) {
+                std::snprintf(g_err, sizeof(g_err), "column %d: Gaussian prior needs finite loc/log_mass and sigma > 0", i);
+                delete m;
+                return GF_ERR_INVALID_ARG;
+            }
+            c.loc[i] = d->loc[i];
+            c.inv_sigma[i] = 1.0 / d->sigma[i];
+            pc += ((-logC) - d->log_mass[i]) - std::log(d->sigma[i]);
+        } else {
+            delete m;
+            return GF_ERR_INVALID_ARG;
+        }
+    }
+    c.prior_const = pc;
+
+    for (int k = 0; k < 3; ++k) { c.src_fixed[k] = d->source_ratio[k]; c.bf[k] = d->bestfit_fr[k]; }
+    c.src_fixed_sum = (d->source_ratio[0] + d->source_ratio[1]) + d->source_ratio[2];
+    // multi_gaussian, llh.py:53-54 + scipy _multivariate.py:514-539: cov = smearing^2 I
+    if (d->mode != GF_MODE_PRIOR_ONLY) {
+        if (!(d->smearing > 0.0) || !finite_all(d->bestfit_fr, 3)) { delete m; return GF_ERR_INVALID_ARG; }
+        const double s = std::pow(d->smearing, 2);
+        c.inv_smear = std::sqrt(1.0 / s);
+        c.gauss_c0 = 3.0 * std::log(2.0 * M_PI) + ((std::log(s) + std::log(s)) + std::log(s));
+    }
+    c.offset = d->offset;
+    c.flat_llh = d->flat_llh;
+
+    GfBsm& b = m->hb;
+    if (d->mode == GF_MODE_BSM_GAUSS) {
+        if (d->nbins < 1 || d->nbins > GF_MAX_BINS || d->texture < GF_TEX_OEU || d->texture > GF_TEX_NONE) {
+            delete m;
+            return GF_ERR_INVALID_ARG;
+        }
+        if (d->texture == GF_TEX_NONE && (d->idx_mm[0] < 0 && !finite_all(d->mm_fixed, 4))) { delete m; return GF_ERR_INVALID_ARG; }
+        b.texture = d->texture;
+        b.dimension = d->dimension;
+        b.nbins = d->nbins;
+        for (int k = 0; k < d->nbins; ++k) {
+            const double e = std::sqrt(d->bin_edges[k] * d->bin_edges[k + 1]);     // fr.py:413
+            if (!(e > 0.0) || !std::isfinite(e)) { delete m; return GF_ERR_INVALID_ARG; }
+            b.centre[k] = e;
+            b.weight[k] = std::fabs(d->bin_edges[k + 1] - d->bin_edges[k]);        // fr.py:414
+            b.inv2e[k] = 1.0 / (2 * e);                                            // fr.py:386
+            b.epow[k] = std::pow(e, (double)(d->dimension - 3));                   // fr.py:394
+        }
+        if (d->texture != GF_TEX_NONE) {
+            const double z = 0. + 1e-9;                                            // fr.py:370
+            double ang[4];
+            switch (d->texture) {
+            case GF_TEX_OEU: ang[0] = 0.5; ang[1] = 1.0; ang[2] = z; ang[3] = z; break;
+            case GF_TEX_OET: ang[0] = z; ang[1] = 0.25; ang[2] = z; ang[3] = z; break;
+            default: ang[0] = z; ang[1] = 1.0; ang[2] = 0.5; ang[3] = z; break;
+            }
+            cld u[3][3];
+            mixing_matrix_ld(ang, u);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const cld t1 = u[i][1] * std::conj(u[j][1]);
+                    const cld t2 = u[i][2] * std::conj(u[j][2]);
+                    b.t1_re[3 * i + j] = (double)t1.real(); b.t1_im[3 * i + j] = (double)t1.imag();
+                    b.t2_re[3 * i + j] = (double)t2.real(); b.t2_im[3 * i + j] = (double)t2.imag();
+                }
+        }
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        delete m;
+        std::snprintf(g_err, sizeof(g_err), "no HIP device %d (found %d)", device, ndev);
+        return GF_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete m;
+        std::snprintf(g_err, sizeof(g_err), "device %d is not gfx950", device);
+        return GF_ERR_NO_DEVICE;
+    }
+    m->device = device;
+    m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && d->mode == GF_MODE_BSM_GAUSS) {
+        e = hipMalloc((void**)&m->d_bsm, sizeof(GfBsm));
+        if (e == hipSuccess) e = hipMemcpy(m->d_bsm, &m->hb, sizeof(GfBsm), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        int rc = hip_fail(e, "gf_model_create");
+        gf_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return GF_OK;
+}
+
+void gf_model_destroy(gf_model* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->d_bsm) (void)hipFree(m->d_bsm);
+    if (m->d_theta) (void)hipFree(m->d_theta);
+    if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_status) (void)hipFree(m->d_status);
+    if (m->h_pin) (void)hipHostFree(m->h_pin);
+    delete m;
+}
+
+int gf_model_ndim(const gf_model* m) { return m ? m->c.ndim : -1; }
+
+// ---- host-buffer entry points ------------------------------------------------------------
+static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status,
+                    bool with_llh)
+{
+    if (!m || n < 0 || (n > 0 && (!theta || (with_llh && !lnprob) || (!with_llh && !fr)))) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    GF_HIP(hipSetDevice(m->device));
+    int rc = ensure_staging(m, n);
+    if (rc != GF_OK) return rc;
+    const size_t nd = (size_t)m->c.ndim;
+    double* h_theta = (double*)m->h_pin;
+    double* h_out = h_theta + nd * m->cap;
+    double* h_fr = h_out + m->cap;
+    int32_t* h_st = (int32_t*)(h_fr + 3 * m->cap);
+    std::memcpy(h_theta, theta, sizeof(double) * nd * n);
+    GF_HIP(hipMemcpyAsync(m->d_theta, h_theta, sizeof(double) * nd * n, hipMemcpyHostToDevice, m->stream));
+    double* d_ln = m->d_out;
+    double* d_fr = m->d_out + m->cap;
+    if (with_llh)
+        rc = launch_lnprob(m, m->d_theta, GF_LAYOUT_AOS, n, d_ln, fr ? d_fr : nullptr, status ? m->d_status : nullptr);
+    else
+        rc = launch_propagate(m, m->d_theta, GF_LAYOUT_AOS, n, d_fr, status ? m->d_status : nullptr);
+    if (rc != GF_OK) return rc;
+    if (with_llh) GF_HIP(hipMemcpyAsync(h_out, d_ln, sizeof(double) * n, hipMemcpyDeviceToHost, m->stream));
+    if (fr) GF_HIP(hipMemcpyAsync(h_fr, d_fr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, m->stream));
+    if (status) GF_HIP(hipMemcpyAsync(h_st, m->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+    GF_HIP(hipStreamSynchronize(m->stream));
+    if (with_llh) std::memcpy(lnprob, h_out, sizeof(double) * n);
+    if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
+    if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
+    return GF_OK;
+}
+
+int gf_lnprob_batch(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status)
+{
+    return run_host(m, theta, n, lnprob, fr, status, true);
+}
+
+int gf_propagate_batch(gf_model* m, const double* theta, int64_t n, double* fr, int32_t* status)
+{
+    return run_host(m, theta, n, nullptr, fr, status, false);
+}
+
+int gf_haar_draw(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, double* angles, double* fr)
+{
+    if (!m || n < 0 || (n > 0 && !fr)) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    GF_HIP(hipSetDevice(m->device));
+    double *d_fr = nullptr, *d_ang = nullptr;
+    GF_HIP(hipMalloc((void**)&d_fr, sizeof(double) * 3 * n));
+    if (angles) {
+        hipError_t e = hipMalloc((void**)&d_ang, sizeof(double) * 4 * n);
+        if (e != hipSuccess) { (void)hipFree(d_fr); return hip_fail(e, "hipMalloc(angles)"); }
+    }
+    int rc = gf_haar_draw_device(m, seed, first_draw, n, d_ang, d_fr);
+    hipError_t e = hipSuccess;
+    if (rc == GF_OK) e = hipMemcpyAsync(fr, d_fr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, m->stream);
+    if (rc == GF_OK && e == hipSuccess && angles)
+        e = hipMemcpyAsync(angles, d_ang, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(d_fr);
+    if (d_ang) (void)hipFree(d_ang);
+    if (rc != GF_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "gf_haar_draw");
+    return GF_OK;
+}
+
+// ---- device-resident entry points ----------------------------------------------------------
+int gf_device_alloc(gf_model* m, size_t bytes, void** dptr)
+{
+    if (!m || !dptr) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return GF_OK;
+}
+
+int gf_device_free(gf_model* m, void* dptr)
+{
+    if (!m) return GF_ERR_INVALID_ARG;
+    if (!dptr) return GF_OK;
+    GF_HIP(hipSetDevice(m->device));
+    GF_HIP(hipStreamSynchronize(m->stream));
+    GF_HIP(hipFree(dptr));
+    return GF_OK;
+}
+
+int gf_memcpy_h2d(gf_model* m, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!m || !dst_dev || !src_host) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, m->stream));
+    GF_HIP(hipStreamSynchronize(m->stream));
+    return GF_OK;
+}
+
+int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!m || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
+    GF_HIP(hipStreamSynchronize(m->stream));
+    return GF_OK;
+}
+
+int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,
+                           int32_t* d_status)
+{
+    if (!m || n < 0 || (layout != GF_LAYOUT_AOS && layout != GF_LAYOUT_SOA)) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    int rc = check_dev_ptr(d_theta, 16);
+    if (rc == GF_OK) rc = check_dev_ptr(d_lnprob, 8);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipSetDevice(m->device));
+    return launch_lnprob(m, d_theta, layout, n, d_lnprob, d_fr, d_status);
+}
+
+int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_fr,
+                              int32_t* d_status)
+{
+    if (!m || n < 0 || (layout != GF_LAYOUT_AOS && layout != GF_LAYOUT_SOA)) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    int rc = check_dev_ptr(d_theta, 16);
+    if (rc == GF_OK) rc = check_dev_ptr(d_fr, 8);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipSetDevice(m->device));
+    return launch_propagate(m, d_theta, layout, n, d_fr, d_status);
+}
+
+int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, double* d_angles, double* d_fr)
+{
+    if (!m || n < 0 || first_draw < 0) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    int rc = check_dev_ptr(d_fr, 8);
+    if (rc == GF_OK && d_angles) rc = check_dev_ptr(d_angles, 32);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipSetDevice(m->device));
+    hipError_t e = gf_launch_haar(m->c, seed, first_draw, n, d_angles, d_fr, m->cus, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "haar launch");
+    return GF_OK;
+}
+
+int gf_model_sync(gf_model* m)
+{
+    if (!m) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipStreamSynchronize(m->stream));
+    return GF_OK;
+}
+
+int gf_event_create(void** ev)
+{
+    if (!ev) return GF_ERR_INVALID_ARG;
+    hipEvent_t e;
+    GF_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return GF_OK;
+}
+
+int gf_event_destroy(void* ev)
+{
+    if (!ev) return GF_OK;
+    GF_HIP(hipEventDestroy((hipEvent_t)ev));
+    return GF_OK;
+}
+
+int gf_event_record(gf_model* m, void* ev)
+{
+    if (!m || !ev) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipEventRecord((hipEvent_t)ev, m->stream));
+    return GF_OK;
+}
+
+int gf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms)
+{
+    if (!ev_start || !ev_stop || !ms) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    GF_HIP(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return GF_OK;
+}
+
+}  // extern "C"

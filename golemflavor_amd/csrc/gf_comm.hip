@@ -1,0 +1,133 @@
+// gf_comm.hip -- the multi-GPU plumbing of the C ABI: one process per GPU, RCCL over xGMI.
+// Chains (grid points) are independent, so the data path needs no collective; what is exchanged is
+// the packed model descriptors at start (broadcast, ~1 KB each) and the chain blocks at the end
+// (all-gather) -- the role HTCondor + a shared filesystem play in the reference
+// (submitter/mc_texture_dag.py:57-71, submitter/sens_dag.py:75-95).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/golemflavor_hip.h"
+
+static_assert(GF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RCCL unique id size changed");
+
+struct gf_comm {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, nranks = 1, device = 0;
+};
+
+namespace {
+thread_local char g_cerr[256] = "";
+int comm_fail(const char* what, const char* msg)
+{
+    std::snprintf(g_cerr, sizeof(g_cerr), "%s: %s", what, msg);
+    return GF_ERR_COMM;
+}
+#define GF_NCCL(call)                                                        \
+    do {                                                                     \
+        ncclResult_t r_ = (call);                                            \
+        if (r_ != ncclSuccess) return comm_fail(#call, ncclGetErrorString(r_)); \
+    } while (0)
+#define GF_CHIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return comm_fail(#call, hipGetErrorString(e_)); \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* gf_comm_last_error(void) { return g_cerr; }
+
+int gf_comm_unique_id(uint8_t id[GF_COMM_ID_BYTES])
+{
+    if (!id) return GF_ERR_INVALID_ARG;
+    ncclUniqueId uid;
+    GF_NCCL(ncclGetUniqueId(&uid));
+    std::memcpy(id, &uid, GF_COMM_ID_BYTES);
+    return GF_OK;
+}
+
+int gf_comm_create(const uint8_t id[GF_COMM_ID_BYTES], int rank, int nranks, int device, gf_comm** out)
+{
+    if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    gf_comm* c = new (std::nothrow) gf_comm();
+    if (!c) return GF_ERR_ALLOC;
+    c->rank = rank; c->nranks = nranks; c->device = device;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, GF_COMM_ID_BYTES);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return comm_fail("gf_comm_create", hipGetErrorString(e)); }
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return comm_fail("ncclCommInitRank", ncclGetErrorString(r));
+    }
+    *out = c;
+    return GF_OK;
+}
+
+void gf_comm_destroy(gf_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gf_comm_broadcast(gf_comm* c, void* host_buf, size_t bytes, int root)
+{
+    if (!c || !host_buf || root < 0 || root >= c->nranks) return GF_ERR_INVALID_ARG;
+    if (bytes == 0) return GF_OK;
+    GF_CHIP(hipSetDevice(c->device));
+    void* d = nullptr;
+    GF_CHIP(hipMalloc(&d, bytes));
+    int rc = GF_OK;
+    hipError_t e = hipSuccess;
+    if (c->rank == root) e = hipMemcpyAsync(d, host_buf, bytes, hipMemcpyHostToDevice, c->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = ncclBroadcast(d, d, bytes, ncclChar, root, c->comm, c->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(host_buf, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    if (r != ncclSuccess) rc = comm_fail("ncclBroadcast", ncclGetErrorString(r));
+    else if (e != hipSuccess) rc = comm_fail("gf_comm_broadcast", hipGetErrorString(e));
+    (void)hipFree(d);
+    return rc;
+}
+
+int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank)
+{
+    if (!c || !d_send || !d_recv) return GF_ERR_INVALID_ARG;
+    if (bytes_per_rank == 0) return GF_OK;
+    GF_CHIP(hipSetDevice(c->device));
+    GF_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, c->comm, c->stream));
+    GF_CHIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
+int gf_comm_barrier(gf_comm* c)
+{
+    if (!c) return GF_ERR_INVALID_ARG;
+    GF_CHIP(hipSetDevice(c->device));
+    int* d = nullptr;
+    GF_CHIP(hipMalloc((void**)&d, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), c->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = ncclAllReduce(d, d, 1, ncclInt, ncclSum, c->comm, c->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (r != ncclSuccess) return comm_fail("ncclAllReduce", ncclGetErrorString(r));
+    if (e != hipSuccess) return comm_fail("gf_comm_barrier", hipGetErrorString(e));
+    return GF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// Per-run constants derived from gf_model_desc by gf_model_create (host) and consumed by the
+// kernels.  Small ones travel by value as kernel arguments (scalar loads -> SGPRs); the BSM bin
+// tables live in one device buffer per model.
+#pragma once
+#include <stdint.h>
+
+#define GF_MAX_DIM 16
+#define GF_MAX_BINS 64
+
+// Priors + named-column map + Gaussian likelihood constants: every mode needs these.
+struct GfCommon {
+    int32_t ndim;
+    int32_t mode;
+    int32_t idx_sm[4];
+    int32_t idx_mass[2];
+    int32_t idx_src[2];
+    int32_t idx_scale;
+    int32_t idx_mm[4];
+    int32_t idx_gamma;
+    int32_t pad_;
+    double lo[GF_MAX_DIM];
+    double hi[GF_MAX_DIM];
+    double loc[GF_MAX_DIM];
+    double inv_sigma[GF_MAX_DIM];   // 0 for UNIFORM columns: their z is forced to 0
+    double prior_const;             // sum over non-uniform columns of -log sqrt(2pi) - log_mass - log sigma
+    double sm_fixed[4];
+    double mass_fixed[2];
+    double src_fixed[3];
+    double src_fixed_sum;           // fp64 left-to-right sum of src_fixed (np.sum, fr.py:535)
+    double scale_fixed;
+    double mm_fixed[4];
+    double bf[3];
+    double inv_smear;               // sqrt(1 / smearing^2)      (scipy _PSD: U = u * sqrt(1/s))
+    double gauss_c0;                // 3 log(2 pi) + log_pdet
+    double offset;
+    double flat_llh;
+};
+
+// BSM tables (device memory, read with uniform indices -> scalar loads).
+struct GfBsm {
+    int32_t texture;
+    int32_t dimension;
+    int32_t nbins;
+    int32_t pad_;
+    // Fixed textures (fr.py:370-378): U~ diag(0, sc1, sc2) U~^dagger = sc1 T1 + sc2 T2 with the rank-1
+    // projectors T1 = u~_1 u~_1^dagger, T2 = u~_2 u~_2^dagger (columns 1 and 2 of U~), precomputed in
+    // long double on the host.  For texture NONE they are rebuilt per walker from the sampled angles.
+    double t1_re[9], t1_im[9];
+    double t2_re[9], t2_im[9];
+    double inv2e[GF_MAX_BINS];      // 1 / (2 E_k)                fr.py:386
+    double epow[GF_MAX_BINS];       // E_k ** (d - 3)             fr.py:394
+    double weight[GF_MAX_BINS];     // |b_{k+1} - b_k|            fr.py:414 (the 1/(b_N - b_0) factor cancels in fr.py:457)
+    double centre[GF_MAX_BINS];     // sqrt(b_k b_{k+1})          fr.py:413
+};

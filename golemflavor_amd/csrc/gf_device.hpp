@@ -1,0 +1,190 @@
+// gf_device.hpp -- device-side building blocks shared by the kernels (gf_kernels.hip, gf_bsm.hip).
+// Reference formulas are cited per function (file:line under the reference tree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf_consts.h"
+
+#define GF_WAVE 64
+#define GF_BLOCK 256
+#define GF_WAVES_PER_BLOCK (GF_BLOCK / GF_WAVE)
+
+namespace gfdev {
+
+constexpr int ST_OK = 0, ST_OUT_OF_PRIOR = 1, ST_NON_UNITARY = 2, ST_NAN = 3;
+constexpr int MODE_PRIOR_ONLY = 0, MODE_SM_GAUSS = 1, MODE_BSM_GAUSS = 2;
+
+__device__ __forceinline__ double gf_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+__device__ __forceinline__ double gf_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// ---------------------------------------------------------------------------------------------
+// Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).
+// AoS: the block is contiguous in memory -> 16-B vector loads, lane-contiguous.
+// SoA: each lane loads its own ndim values (8-B, lane-contiguous per column).
+template <int NDIM>
+__device__ __forceinline__ void stage_theta(const double* __restrict__ theta, int layout, int64_t n,
+                                            int64_t w0, int ndim_rt, double* tile, int lane)
+{
+    const int ndim = NDIM ? NDIM : ndim_rt;
+    const int64_t rows = (n - w0 < GF_WAVE) ? (n - w0) : GF_WAVE;
+    if (layout == 0) {
+        const int64_t count = rows * ndim;                    // doubles in this wave's span
+        const double* src = theta + w0 * ndim;                // 512*ndim-byte aligned relative to theta
+        const int nvec = (GF_WAVE * ndim + 1) / 2;            // 16-B vectors in a full tile
+#pragma unroll
+        for (int j = 0; j < (NDIM ? (NDIM + 1) / 2 : (GF_MAX_DIM / 2)); ++j) {
+            const int v = j * GF_WAVE + lane;
+            if (!NDIM && v >= nvec) break;
+            const int64_t d = 2 * (int64_t)v;
+            if (d + 1 < count) {
+                const double2 x = *reinterpret_cast<const double2*>(src + d);
+                *reinterpret_cast<double2*>(tile + d) = x;
+            } else if (d < count) {
+                tile[d] = src[d];
+            }
+        }
+    } else {
+        if (lane < rows) {
+#pragma unroll
+            for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
+                if (!NDIM && d >= ndim) break;
+                tile[lane * ndim + d] = theta[(int64_t)d * n + w0 + lane];
+            }
+        }
+    }
+    // same-wave LDS write -> read: in-order in hardware; keep the compiler from reordering.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
+// golemflavor/llh.py:65-91 lnprior.  Closed box (NaN fails), then sum of truncated-normal logpdfs:
+// scipy: ((-z^2/2 - log sqrt(2pi)) - log_mass) - log sigma, z = (x - loc)/sigma; the three constants
+// are pre-summed on the host (GfCommon::prior_const).  UNIFORM columns have inv_sigma = 0.
+template <int NDIM>
+__device__ __forceinline__ bool lnprior(const GfCommon& c, const double* row, double& lp)
+{
+    const int ndim = NDIM ? NDIM : c.ndim;
+    bool inbox = true;
+    double acc = 0.0;
+#pragma unroll
+    for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double x = row[d];
+        inbox = inbox && (x >= c.lo[d]) && (x <= c.hi[d]);
+        const double z = (x - c.loc[d]) * c.inv_sigma[d];
+        acc = fma(-0.5 * z, z, acc);
+    }
+    lp = acc + c.prior_const;
+    return inbox;
+}
+
+// ---------------------------------------------------------------------------------------------
+// |U_ai|^2 of the PMNS matrix from (s12^2, c13^4, s23^2, delta): golemflavor/fr.py:116-162 in the
+// algebraic form of SURVEY.md A.2.  The decoherent propagation only needs the moduli, which depend on
+// delta through cos(delta) alone:
+//   |Ue1|^2 = c12^2 c13^2, |Ue2|^2 = s12^2 c13^2, |Ue3|^2 = s13^2,
+//   |Um3|^2 = s23^2 c13^2, |Ut3|^2 = c23^2 c13^2,
+//   |Um1|^2 = s12^2 c23^2 + c12^2 s23^2 s13^2 + 2 J cos d,   |Um2|^2 = c12^2 c23^2 + s12^2 s23^2 s13^2 - 2 J cos d,
+//   |Ut1|^2 = s12^2 s23^2 + c12^2 c23^2 s13^2 - 2 J cos d,   |Ut2|^2 = c12^2 s23^2 + s12^2 c23^2 s13^2 + 2 J cos d,
+// J = s12 c12 s23 c23 s13 = sqrt(s12^2 c12^2 s23^2 c23^2 s13^2)   (all five factors are >= 0: the
+// reference takes the angles in [0, pi/2] via asin/acos of a square root, fr.py:145-147).
+__device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23_2, double dcp, double p[3][3])
+{
+    const double c13_2 = sqrt(c13_4);
+    const double s13_2 = 1.0 - c13_2;
+    const double c12_2 = 1.0 - s12_2;
+    const double c23_2 = 1.0 - s23_2;
+    const double a = s12_2 * c23_2, b = c12_2 * s23_2;
+    const double e = c12_2 * c23_2, f = s12_2 * s23_2;
+    const double j2 = 2.0 * sqrt((a * b) * s13_2) * cos(dcp);
+    p[0][0] = c12_2 * c13_2;
+    p[0][1] = s12_2 * c13_2;
+    p[0][2] = s13_2;
+    p[1][0] = fma(b, s13_2, a) + j2;
+    p[1][1] = fma(f, s13_2, e) - j2;
+    p[1][2] = s23_2 * c13_2;
+    p[2][0] = fma(e, s13_2, f) - j2;
+    p[2][1] = fma(a, s13_2, b) + j2;
+    p[2][2] = c23_2 * c13_2;
+}
+
+// golemflavor/fr.py:82-113 angles_to_fr: (sin^4 phi, cos 2psi) -> composition.  sin^2(acos(c)/2) =
+// (1-c)/2 exactly, so no trigonometry is needed.
+__device__ __forceinline__ void angles_to_fr(double sphi4, double c2psi, double f[3])
+{
+    const double sphi2 = sqrt(sphi4);
+    const double spsi2 = 0.5 * (1.0 - c2psi);
+    const double cpsi2 = 1.0 - spsi2;
+    f[0] = fabs(sphi2 * cpsi2);
+    f[1] = fabs(sphi2 * spsi2);
+    f[2] = fabs(1.0 - sphi2);
+}
+
+// golemflavor/fr.py:502-536 u_to_fr: out_b = sum_a sum_i |U_ai|^2 |U_bi|^2 src_a / sum(src)
+__device__ __forceinline__ void propagate(const double p[3][3], const double src[3], double src_sum, double out[3])
+{
+    // P_ab = sum_i p[a][i] p[b][i] is symmetric: six dot products
+    const double p00 = fma(p[0][2], p[0][2], fma(p[0][1], p[0][1], p[0][0] * p[0][0]));
+    const double p11 = fma(p[1][2], p[1][2], fma(p[1][1], p[1][1], p[1][0] * p[1][0]));
+    const double p22 = fma(p[2][2], p[2][2], fma(p[2][1], p[2][1], p[2][0] * p[2][0]));
+    const double p01 = fma(p[0][2], p[1][2], fma(p[0][1], p[1][1], p[0][0] * p[1][0]));
+    const double p02 = fma(p[0][2], p[2][2], fma(p[0][1], p[2][1], p[0][0] * p[2][0]));
+    const double p12 = fma(p[1][2], p[2][2], fma(p[1][1], p[2][1], p[1][0] * p[2][0]));
+    const double inv = 1.0 / src_sum;
+    out[0] = fma(p02, src[2], fma(p01, src[1], p00 * src[0])) * inv;
+    out[1] = fma(p12, src[2], fma(p11, src[1], p01 * src[0])) * inv;
+    out[2] = fma(p22, src[2], fma(p12, src[1], p02 * src[0])) * inv;
+}
+
+// golemflavor/llh.py:32-54 multi_gaussian = log(mvn.pdf) + offset.  scipy evaluates
+// logpdf = -0.5 (3 log 2pi + log_pdet + maha) and then exp(); the reference takes log() of that, so
+// below the fp64 underflow wall the value is quantised (subnormal band, logpdf in (-745.13, -708.40))
+// or -inf.  Emulated: y = exp(logpdf) / 2^-1074 rounded to an integer count of subnormal ulps.
+__device__ __forceinline__ double log_of_exp(double x)
+{
+    if (x >= -708.3964185322641) return x;              // exp(x) is a normal number: log(exp(x)) == x to 1 ulp
+    const double HI = 744.4400719213812, LO = 4.422444340918698e-14;   // 1074 ln 2 = HI + LO
+    const double t = x + HI;                            // exact (both multiples of 2^-43, |t| < 64)
+    const double y = exp(t) * (1.0 + LO);
+    const double k = rint(y);
+    if (!(k >= 1.0)) return (x != x) ? x : -gf_inf();   // underflows to zero -> log(0) = -inf
+    return (log(k) - HI) - LO;
+}
+
+__device__ __forceinline__ double gauss_llh(const GfCommon& c, const double fr[3])
+{
+    const double d0 = (fr[0] - c.bf[0]) * c.inv_smear;
+    const double d1 = (fr[1] - c.bf[1]) * c.inv_smear;
+    const double d2 = (fr[2] - c.bf[2]) * c.inv_smear;
+    const double maha = fma(d2, d2, fma(d1, d1, d0 * d0));
+    const double logpdf = -0.5 * (c.gauss_c0 + maha);
+    return log_of_exp(logpdf) + c.offset;
+}
+
+__device__ __forceinline__ double pick(const double* row, int idx, double fixed)
+{
+    return idx >= 0 ? row[idx] : fixed;                 // idx is wave-uniform (kernel argument)
+}
+
+// SM measured composition for one walker: examples/inference.ipynb:316-328
+__device__ __forceinline__ void sm_composition(const GfCommon& c, const double* row, double fr[3])
+{
+    double p[3][3];
+    pmns_abs2(pick(row, c.idx_sm[0], c.sm_fixed[0]), pick(row, c.idx_sm[1], c.sm_fixed[1]),
+              pick(row, c.idx_sm[2], c.sm_fixed[2]), pick(row, c.idx_sm[3], c.sm_fixed[3]), p);
+    double src[3], src_sum;
+    if (c.idx_src[0] >= 0) {
+        angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
+        src_sum = (src[0] + src[1]) + src[2];
+    } else {
+        src[0] = c.src_fixed[0]; src[1] = c.src_fixed[1]; src[2] = c.src_fixed[2];
+        src_sum = c.src_fixed_sum;
+    }
+    propagate(p, src, src_sum, fr);
+}
+
+
+}  // namespace gfdev

@@ -1,0 +1,212 @@
+// gf_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): the per-walker physics of
+// GolemFlavor's ensemble log-posterior.  fp64 throughout; no MFMA (3x3 matrices, HBM/VALU bound).
+//
+// Data movement.  theta arrives as emcee lays it out, AoS [n][ndim] fp64.  A wave owns 64
+// consecutive walkers = one contiguous 512*ndim-byte span; it pulls that span with 16-byte
+// lane-contiguous loads (1 KiB per wave-instruction, every byte of every 128-B line used once) into a
+// wave-private LDS tile, then each lane reads back its own row.  Named parameters (s_12_2, dcp, ...)
+// are then LDS reads at a *uniform* column index, so the sampled/fixed split costs no register
+// indexing.  Waves never synchronise with each other (no s_barrier): the only ordering needed is
+// within one wave, and LDS executes a wave's instructions in order.
+//
+// Reference formulas are cited per function (file:line under the reference tree); the algebraic forms
+// are those of SURVEY.md Appendix A.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf_consts.h"
+#include "gf_launch.h"
+
+#include "gf_device.hpp"
+
+namespace {
+using namespace gfdev;
+
+// ---------------------------------------------------------------------------------------------
+// lnprob for MODE_PRIOR_ONLY and MODE_SM_GAUSS.  One lane per walker, grid-stride over 64-walker
+// wave tiles.
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm(const GfCommon c, const double* __restrict__ theta,
+                                                         int layout, int64_t n, double* __restrict__ lnprob,
+                                                         double* __restrict__ fr_out, int32_t* __restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    const int wave = threadIdx.x / GF_WAVE;
+    const int ndim = NDIM ? NDIM : c.ndim;
+    double* tile = tiles[wave];
+    const int64_t ntiles = (n + GF_WAVE - 1) / GF_WAVE;
+    const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
+        const int64_t w0 = t * GF_WAVE;
+        stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane);
+        const int64_t i = w0 + lane;
+        if (i < n) {
+            const double* row = tile + lane * ndim;
+            double lp;
+            const bool inbox = lnprior<NDIM>(c, row, lp);
+            double fr[3] = {gf_nan(), gf_nan(), gf_nan()};
+            double val;
+            int st = ST_OK;
+            if (!inbox) {
+                val = -gf_inf();                         // llh.py:78 / ipynb:360-361
+                st = ST_OUT_OF_PRIOR;
+            } else if (MODE == MODE_PRIOR_ONLY) {
+                val = lp + c.flat_llh;                   // mc_unitary.py:131,139
+            } else {
+                sm_composition(c, row, fr);
+                val = lp + gauss_llh(c, fr);             // ipynb:364
+                if (val != val) st = ST_NAN;
+            }
+            lnprob[i] = val;
+            if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
+            if (status) status[i] = st;
+        }
+        // the tile is rewritten by the same wave next iteration; keep its reads ahead of those writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Chain post-processing: composition only (scripts/mc_unitary.py:189-193).
+template <int NDIM>
+__global__ __launch_bounds__(GF_BLOCK) void k_propagate_sm(const GfCommon c, const double* __restrict__ theta,
+                                                            int layout, int64_t n, double* __restrict__ fr_out,
+                                                            int32_t* __restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    const int wave = threadIdx.x / GF_WAVE;
+    const int ndim = NDIM ? NDIM : c.ndim;
+    double* tile = tiles[wave];
+    const int64_t ntiles = (n + GF_WAVE - 1) / GF_WAVE;
+    const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
+        const int64_t w0 = t * GF_WAVE;
+        stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane);
+        const int64_t i = w0 + lane;
+        if (i < n) {
+            double fr[3];
+            sm_composition(c, tile + lane * ndim, fr);
+            fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2];
+            if (status) status[i] = (fr[0] != fr[0] || fr[1] != fr[1] || fr[2] != fr[2]) ? ST_NAN : ST_OK;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so draw i is a pure function of (seed, i).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)m1;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)m0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
+{
+    // 53 random bits -> [0,1): (hi >> 5) * 2^26 + (lo >> 6), scaled by 2^-53
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// Haar draws: angles ~ U([0,1]^3 x [0,2pi]) (the flat prior of scripts/mc_unitary.py:35-40), then
+// angles_to_u -> u_to_fr(source_ratio) (mc_unitary.py:189-193).  24 B written per draw.
+__global__ __launch_bounds__(GF_BLOCK) void k_haar(const GfCommon c, uint64_t seed, int64_t first, int64_t n,
+                                                   double* __restrict__ angles, double* __restrict__ fr_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * GF_BLOCK;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int64_t i = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint64_t ctr = (uint64_t)(first + i);
+        uint32_t a[4], b[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, k0, k1, a);
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, k0, k1, b);
+        const double s12_2 = u53(a[0], a[1]);
+        const double c13_4 = u53(a[2], a[3]);
+        const double s23_2 = u53(b[0], b[1]);
+        const double dcp = 6.283185307179586 * u53(b[2], b[3]);
+        double p[3][3], fr[3];
+        pmns_abs2(s12_2, c13_4, s23_2, dcp, p);
+        const double src[3] = {c.src_fixed[0], c.src_fixed[1], c.src_fixed[2]};
+        propagate(p, src, c.src_fixed_sum, fr);
+        fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2];
+        if (angles) {
+            double4 v; v.x = s12_2; v.y = c13_4; v.z = s23_2; v.w = dcp;
+            *reinterpret_cast<double4*>(angles + 4 * i) = v;
+        }
+    }
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cus)
+{
+    int64_t blocks = (work_items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)cus * 8;                // 8 x 256-thread blocks per CU keeps the chip full
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int NDIM>
+hipError_t launch_lnprob_sm_n(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
+                              double* fr, int32_t* status, int cus, hipStream_t s)
+{
+    const int grid = grid_for(n, GF_BLOCK, cus);
+    if (c.mode == MODE_PRIOR_ONLY)
+        hipLaunchKernelGGL((k_lnprob_sm<NDIM, MODE_PRIOR_ONLY>), dim3(grid), dim3(GF_BLOCK), 0, s, c, theta, layout, n, lnprob, fr, status);
+    else
+        hipLaunchKernelGGL((k_lnprob_sm<NDIM, MODE_SM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, s, c, theta, layout, n, lnprob, fr, status);
+    return hipGetLastError();
+}
+
+template <int NDIM>
+hipError_t launch_propagate_sm_n(const GfCommon& c, const double* theta, int layout, int64_t n, double* fr,
+                                 int32_t* status, int cus, hipStream_t s)
+{
+    const int grid = grid_for(n, GF_BLOCK, cus);
+    hipLaunchKernelGGL((k_propagate_sm<NDIM>), dim3(grid), dim3(GF_BLOCK), 0, s, c, theta, layout, n, fr, status);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
+                               double* fr, int32_t* status, int cus, hipStream_t s)
+{
+    switch (c.ndim) {
+    case 4: return launch_lnprob_sm_n<4>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    case 6: return launch_lnprob_sm_n<6>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    case 7: return launch_lnprob_sm_n<7>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    case 12: return launch_lnprob_sm_n<12>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    default: return launch_lnprob_sm_n<0>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    }
+}
+
+hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* fr,
+                                  int32_t* status, int cus, hipStream_t s)
+{
+    switch (c.ndim) {
+    case 4: return launch_propagate_sm_n<4>(c, theta, layout, n, fr, status, cus, s);
+    case 6: return launch_propagate_sm_n<6>(c, theta, layout, n, fr, status, cus, s);
+    default: return launch_propagate_sm_n<0>(c, theta, layout, n, fr, status, cus, s);
+    }
+}
+
+hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,
+                          int cus, hipStream_t s)
+{
+    const int grid = grid_for(n, GF_BLOCK, cus);
+    hipLaunchKernelGGL(k_haar, dim3(grid), dim3(GF_BLOCK), 0, s, c, seed, first, n, angles, fr);
+    return hipGetLastError();
+}

@@ -1,0 +1,17 @@
+// Internal launch interface between the C ABI (gf_capi.hip) and the kernels (gf_kernels.hip,
+// gf_bsm.hip).  All launches are asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf_consts.h"
+
+hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
+                               double* fr, int32_t* status, int cus, hipStream_t s);
+hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* fr,
+                                  int32_t* status, int cus, hipStream_t s);
+hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,
+                          int cus, hipStream_t s);
+// BSM (flux-averaged) path; `with_llh` = 0 -> composition only (propagate), 1 -> lnprob
+hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, const GfBsm& h_bsm, const double* theta, int layout,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s);

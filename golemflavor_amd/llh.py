@@ -1,0 +1,89 @@
+"""The log-posterior callback, GPU-evaluated: drop-in for the callables the reference hands to
+emcee (`partial(ln_prob, ...)`: examples/inference.ipynb:356-371, golemflavor/llh.py:121-130,
+scripts/mc_unitary.py:134-143, scripts/mc_texture.py:161-170).
+
+`LnProb(theta)` keeps the reference convention for a single walker -- `theta` of length ndim ->
+Python float, `-inf` outside the box prior, AssertionError on a length mismatch or on a
+non-unitary BSM mixing matrix -- and additionally accepts a whole ensemble `(n, ndim)` ->
+`(n,)` array in ONE kernel launch (emcee-3's `vectorize=True` convention), which is what
+`golemflavor_amd.mcmc.EnsembleSampler` uses.
+"""
+import numpy as np
+
+from . import _lib
+from . import fr as fr_utils
+from .descriptor import compile_model
+from .enums import ParamTag, Texture
+from .model import Model
+
+__all__ = ["LnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior"]
+
+
+class LnProb:
+    vectorized = True          # tells golemflavor_amd.mcmc.EnsembleSampler to batch the ensemble
+
+    def __init__(self, desc, device=0, on_nonunitary="raise", check_unitarity=True):
+        if on_nonunitary not in ("raise", "-inf"):
+            raise ValueError("on_nonunitary must be 'raise' or '-inf'")
+        self.model = Model(desc, device=device)
+        self.ndim = self.model.ndim
+        self.on_nonunitary = on_nonunitary
+        self.check_unitarity = bool(check_unitarity) and self.model.mode == _lib.GF_MODE_BSM_GAUSS
+        self.ncalls = 0
+        self.nevals = 0
+
+    def __call__(self, theta):
+        single = np.ndim(theta) == 1
+        if self.check_unitarity:
+            lp, st = self.model.lnprob(theta, want_status=True)
+            bad = st == _lib.GF_ST_NON_UNITARY
+            if bad.any():
+                if self.on_nonunitary == "raise":
+                    # reference: AssertionError out of test_unitarity (fr.py:493-498)
+                    th = np.atleast_2d(np.asarray(theta, dtype=float))[np.argmax(bad)]
+                    raise AssertionError("Matrix is not unitary!\ntheta\n{0}".format(th))
+                lp = np.where(bad, -np.inf, lp)
+        else:
+            lp = self.model.lnprob(theta, want_status=False)
+        self.ncalls += 1
+        self.nevals += lp.shape[0]
+        return float(lp[0]) if single else lp
+
+    def close(self):
+        self.model.close()
+
+
+def notebook_ln_prob(asimov_paramset, llh_paramset, device=0):
+    """The posterior of examples/inference.ipynb (cells 21 and 23): lnprior + Gaussian flavor
+    likelihood of u_to_fr(angles_to_fr(source angles), angles_to_u(mixing angles)) around the
+    Asimov composition.  Smearing = asimov_paramset[first BESTFIT].std (ipynb:333)."""
+    bestfit = asimov_paramset.from_tag(ParamTag.BESTFIT)
+    bf = fr_utils.angles_to_fr(bestfit.values)                 # ipynb:330
+    desc = compile_model(llh_paramset, "SM_GAUSS", bestfit_fr=bf, smearing=bestfit[0].std)
+    return LnProb(desc, device=device)
+
+
+def bsm_ln_prob(args, asimov_paramset, llh_paramset, smearing=0.02, device=0, **kw):
+    """golemflavor/llh.py:121-130 `ln_prob(theta, args, asimov_paramset, llh_paramset)` with the
+    GolemFit likelihood replaced by the Gaussian substitute the README sanctions
+    (README.md:70-74): multi_gaussian(measured, angles_to_fr(asimov BESTFIT angles), smearing).
+    `args` needs: source_ratio, dimension, texture, binning (edges)."""
+    bf = fr_utils.angles_to_fr(asimov_paramset.from_tag(ParamTag.BESTFIT, values=True))
+    desc = compile_model(llh_paramset, "BSM_GAUSS", bestfit_fr=bf, smearing=smearing,
+                         source_ratio=args.source_ratio, texture=args.texture,
+                         dimension=args.dimension, binning=args.binning)
+    return LnProb(desc, device=device, **kw)
+
+
+def prior_ln_prob(llh_paramset, device=0, flat_llh=1.0):
+    """scripts/mc_unitary.py:134-143 / mc_texture.py:161-170: lnprior + flat likelihood (1.0)."""
+    return LnProb(compile_model(llh_paramset, "PRIOR_ONLY", flat_llh=flat_llh), device=device)
+
+
+def lnprior(theta, paramset, device=0):
+    """golemflavor/llh.py:65-91 for one theta or a batch, GPU-evaluated."""
+    f = prior_ln_prob(paramset, device=device, flat_llh=0.0)
+    try:
+        return f(theta)
+    finally:
+        f.close()

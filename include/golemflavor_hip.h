@@ -1,0 +1,182 @@
+/*
+ * golemflavor_hip.h -- C ABI of libgolemhip.so, the MI355X (gfx950) evaluation engine for
+ * GolemFlavor's ensemble log-posterior callback.
+ *
+ * The reference has no FFI: the hot path sits behind a Python callable `ln_prob(theta) -> float`
+ * that emcee calls once per walker per step (golemflavor/mcmc.py:27-41).  Each entry point below
+ * names the reference interface it replaces (file:line under the reference tree).  Everything is
+ * plain pointers and sizes; no torch, no C++ types.  The Python side binds this header with ctypes
+ * (golemflavor_amd/_lib.py); INTEGRATION.md shows the stub a GolemFlavor maintainer would add.
+ *
+ * Conventions
+ *   - every function returns a gf_error (0 = GF_OK) and never throws; gf_strerror() explains it;
+ *   - arrays are caller-owned, fp64, row-major; theta is [n][ndim] exactly as emcee hands it over;
+ *   - per-walker outcomes travel in `status` (gf_status), not in the return code;
+ *   - a gf_model is bound to one device and one HIP stream; calls on one model are serialised by
+ *     that stream, different models may be driven from different host threads;
+ *   - there is NO CPU fallback: without a gfx950 device gf_model_create returns GF_ERR_NO_DEVICE.
+ */
+#ifndef GOLEMFLAVOR_HIP_H
+#define GOLEMFLAVOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_ABI_VERSION 1
+#define GF_MAX_DIM 16
+#define GF_MAX_BINS 64
+
+typedef enum gf_error {
+    GF_OK = 0,
+    GF_ERR_INVALID_ARG = 1,   /* NULL pointer, ndim out of range, inconsistent descriptor      */
+    GF_ERR_NO_DEVICE = 2,     /* no HIP device / not gfx950                                     */
+    GF_ERR_HIP = 3,           /* a HIP runtime call failed; gf_last_hip_error() has the string  */
+    GF_ERR_ALLOC = 4,
+    GF_ERR_COMM = 5,          /* RCCL failure                                                   */
+    GF_ERR_UNSUPPORTED = 6
+} gf_error;
+
+/* per-walker outcome.  Reference behaviour: OUT_OF_PRIOR -> ln_prob returns -inf (llh.py:74-78,
+ * ipynb:360-361); NON_UNITARY -> AssertionError raised inside params_to_BSMu (fr.py:398-399,
+ * 493-498); the Python wrapper re-raises it unless told to map it to -inf. */
+typedef enum gf_status {
+    GF_ST_OK = 0,
+    GF_ST_OUT_OF_PRIOR = 1,
+    GF_ST_NON_UNITARY = 2,
+    GF_ST_NAN = 3
+} gf_status;
+
+/* golemflavor/enums.py:39-42 (same integer values) */
+typedef enum gf_prior_kind { GF_PRIOR_UNIFORM = 1, GF_PRIOR_GAUSSIAN = 2, GF_PRIOR_LIMITEDGAUSS = 3 } gf_prior_kind;
+/* golemflavor/enums.py:59-63 (same integer values) */
+typedef enum gf_texture { GF_TEX_OEU = 1, GF_TEX_OET = 2, GF_TEX_OUT = 3, GF_TEX_NONE = 4 } gf_texture;
+
+typedef enum gf_mode {
+    GF_MODE_PRIOR_ONLY = 0,  /* lnprior + flat llh: scripts/mc_unitary.py:121-143, mc_texture.py:148-170 */
+    GF_MODE_SM_GAUSS = 1,    /* notebook posterior: examples/inference.ipynb:307-338,356-364            */
+    GF_MODE_BSM_GAUSS = 2    /* golemflavor/llh.py:94-130 with the Gaussian substitute for gf.get_llh
+                                (README.md:70-74): flux_averaged_BSMu (fr.py:403-458) -> multi_gaussian  */
+} gf_mode;
+
+/* Layout of a device-resident theta block handed to the *_device entry points. */
+typedef enum gf_layout {
+    GF_LAYOUT_AOS = 0,       /* [n][ndim] row-major: the emcee layout                           */
+    GF_LAYOUT_SOA = 1        /* [ndim][n]: one contiguous column per parameter                  */
+} gf_layout;
+
+/*
+ * Flat model descriptor: what the reference carries in (ParamSet, args, asimov ParamSet), compiled
+ * once per run by golemflavor_amd/descriptor.py.  Replaces the functools.partial-bound state of
+ * `ln_prob` (examples/inference.ipynb:366-371, scripts/fr.py:182-187).
+ */
+typedef struct gf_model_desc {
+    int32_t abi_version;               /* GF_ABI_VERSION                                        */
+    int32_t ndim;                      /* len(llh_paramset), 1..GF_MAX_DIM                      */
+    int32_t mode;                      /* gf_mode                                               */
+    int32_t texture;                   /* gf_texture (BSM only), fr.py:370-378                  */
+    int32_t dimension;                 /* BSM operator dimension d (E^(d-3)), fr.py:394         */
+    int32_t nbins;                     /* energy bins of the flux average, fr.py:413-414        */
+    /* column of theta that holds each named parameter, or -1 = take the *_fixed value          */
+    int32_t idx_sm[4];                 /* s_12_2, c_13_4, s_23_2, dcp (fr.py:116-162)           */
+    int32_t idx_mass[2];               /* m21_2, m3x_2 (fr.py:422-435)                          */
+    int32_t idx_src[2];                /* source flavor angles sin^4(phi), cos(2psi) (fr.py:82) */
+    int32_t idx_scale;                 /* logLam (fr.py:380)                                    */
+    int32_t idx_mm[4];                 /* NP mixing angles when texture == NONE (fr.py:378)     */
+    int32_t idx_gamma;                 /* astroDeltaGamma (llh.py:105); cancels in fr, kept for fidelity */
+    int32_t prior_kind[GF_MAX_DIM];    /* gf_prior_kind per column (llh.py:81-90)               */
+    int32_t reserved_;
+    double lo[GF_MAX_DIM];             /* Param.ranges[0]  (closed box, llh.py:74-78)           */
+    double hi[GF_MAX_DIM];             /* Param.ranges[1]                                       */
+    double loc[GF_MAX_DIM];            /* Param.nominal_value (prior centre)                    */
+    double sigma[GF_MAX_DIM];          /* Param.std                                             */
+    double log_mass[GF_MAX_DIM];       /* log Gaussian mass of the truncation interval (scipy truncnorm) */
+    double sm_fixed[4];                /* defaults: NuFIT point, fr.py:313                      */
+    double mass_fixed[2];              /* defaults: MASS_EIGENVALUES, fr.py:42                  */
+    double source_ratio[3];            /* args.source_ratio when the source is not sampled      */
+    double scale_fixed;
+    double mm_fixed[4];
+    double gamma_fixed;                /* spectral index when astroDeltaGamma is not sampled    */
+    double bestfit_fr[3];              /* injected / best-fit composition (llh.py:32-54)        */
+    double smearing;                   /* Gaussian width (llh.py:53)                            */
+    double offset;                     /* multi_gaussian offset, default -320 (llh.py:32)       */
+    double flat_llh;                   /* value of the flat likelihood, 1.0 (mc_unitary.py:131) */
+    double bin_edges[GF_MAX_BINS + 1]; /* args.binning after process_args (scripts/fr.py:122-124) */
+} gf_model_desc;
+
+typedef struct gf_model gf_model;      /* opaque: device constants + stream + staging buffers   */
+
+/* ---- library / device ------------------------------------------------------------------- */
+int gf_abi_version(void);
+const char* gf_strerror(int err);
+const char* gf_last_hip_error(void);   /* thread-local text of the last failing HIP/RCCL call    */
+int gf_device_count(int* count);
+int gf_device_name(int device, char* buf, size_t buflen);   /* gcnArchName, e.g. "gfx950:..."   */
+
+/* ---- model ------------------------------------------------------------------------------ */
+/* Validates `desc`, derives the per-run constants (prior normalisations, Gaussian constants,
+ * texture matrix, bin tables) and uploads them.  Replaces building the partial-bound ln_prob. */
+int gf_model_create(const gf_model_desc* desc, int device, gf_model** out);
+void gf_model_destroy(gf_model* m);
+int gf_model_ndim(const gf_model* m);
+
+/* ---- the hot path, host buffers --------------------------------------------------------- */
+/* lnprob[i] = ln_prob(theta[i]) for i < n.  Replaces the per-walker Python callback
+ * (examples/inference.ipynb:356-364; golemflavor/llh.py:121-130; scripts/mc_unitary.py:134-143).
+ * `fr` ([n][3], measured composition the likelihood saw) and `status` ([n]) may be NULL.
+ * Synchronous: H2D, one kernel launch, D2H on the model's stream, then a stream sync. */
+int gf_lnprob_batch(gf_model* m, const double* theta, int64_t n,
+                    double* lnprob, double* fr, int32_t* status);
+
+/* fr[i] = measured flavor composition for theta[i]: chain post-processing of
+ * scripts/mc_unitary.py:189-193 (u_to_fr(source_ratio, angles_to_u(x))) and
+ * scripts/mc_texture.py:216-221 (flux_averaged_BSMu).  No priors, no likelihood. */
+int gf_propagate_batch(gf_model* m, const double* theta, int64_t n, double* fr, int32_t* status);
+
+/* n Haar-distributed mixing matrices: angles ~ U([0,1]^3 x [0,2pi]) (the flat-prior posterior that
+ * scripts/mc_unitary.py samples by MCMC), propagated with source_ratio.  Counter-based Philox4x32-10
+ * keyed by (seed, draw index): reproducible and independent of the launch geometry.
+ * `angles` ([n][4]) may be NULL. */
+int gf_haar_draw(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, double* angles, double* fr);
+
+/* ---- device-resident variants (no PCIe in the timed region) ------------------------------ */
+int gf_device_alloc(gf_model* m, size_t bytes, void** dptr);
+int gf_device_free(gf_model* m, void* dptr);
+int gf_memcpy_h2d(gf_model* m, void* dst_dev, const void* src_host, size_t bytes);  /* async + sync */
+int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes);  /* async + sync */
+/* asynchronous on the model's stream; `layout` is a gf_layout */
+int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n,
+                           double* d_lnprob, double* d_fr, int32_t* d_status);
+int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n,
+                              double* d_fr, int32_t* d_status);
+int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n,
+                        double* d_angles, double* d_fr);
+int gf_model_sync(gf_model* m);
+
+/* HIP events on the model's stream (what bench.py times the kernel with) */
+int gf_event_create(void** ev);
+int gf_event_destroy(void* ev);
+int gf_event_record(gf_model* m, void* ev);
+int gf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);  /* synchronises on ev_stop */
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
+/* Independent chains (grid points) shard across ranks with no data-path collective; the only
+ * exchanges are the broadcast of the packed descriptors at start and the gather of the chain blocks
+ * at the end -- the role HTCondor + a shared filesystem play in the reference
+ * (submitter/mc_texture_dag.py:57-71, submitter/sens_dag.py:75-95). */
+typedef struct gf_comm gf_comm;
+#define GF_COMM_ID_BYTES 128
+int gf_comm_unique_id(uint8_t id[GF_COMM_ID_BYTES]);                 /* rank 0; ship to the others out of band */
+int gf_comm_create(const uint8_t id[GF_COMM_ID_BYTES], int rank, int nranks, int device, gf_comm** out);
+void gf_comm_destroy(gf_comm* c);
+int gf_comm_broadcast(gf_comm* c, void* host_buf, size_t bytes, int root);            /* host in/out   */
+int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank); /* device  */
+int gf_comm_barrier(gf_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLEMFLAVOR_HIP_H */

@@ -88,6 +88,9 @@ def lib():
         L.orc_flux_averaged.restype = C.c_int
         L.orc_log_gauss_mass.argtypes = [C.c_double, C.c_double]
         L.orc_log_gauss_mass.restype = C.c_double
+        up = C.POINTER(C.c_uint32)
+        L.orc_philox_raw.argtypes = [up, up, up]
+        L.orc_haar_draw.argtypes = [dp, C.c_uint64, C.c_int64, C.c_int64, dp, dp]
         _lib = L
     return _lib
 
@@ -285,3 +288,18 @@ def flux_averaged_BSMu(model, theta):
     if st == NON_UNITARY:
         raise AssertionError("Matrix is not unitary!")
     return out
+
+
+def philox4x32_10(counter, key):
+    c = (C.c_uint32 * 4)(*counter)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox_raw(c, k, out)
+    return tuple(out)
+
+
+def haar_draw(source_ratio, seed, n, first=0):
+    ang = np.empty((n, 4))
+    fr = np.empty((n, 3))
+    lib().orc_haar_draw(_dp(_vec(source_ratio, 3)), int(seed), int(first), int(n), _dp(ang), _dp(fr))
+    return fr, ang

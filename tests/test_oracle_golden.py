@@ -1,0 +1,139 @@
+"""CPU: pin the oracle (oracle/golem_oracle.c) against the golden vectors generated from the
+reference, and against the in-tree known answers."""
+import numpy as np
+import pytest
+
+from common import BIN_EDGES, TEX_BY_VALUE, notebook_sets, rel_err
+from golemflavor_amd import configs as Cf
+
+Z = 1e-9
+TEX_ANGLES = {1: (0.5, 1.0, Z, Z), 2: (Z, 0.25, Z, Z), 3: (Z, 1.0, 0.5, Z)}
+
+
+def test_g1_angles_to_u(golden, oracle):
+    u = np.array([oracle.angles_to_u(a) for a in golden["g1_angles"]])
+    assert np.abs(u.real - golden["g1_u_re"]).max() <= 2e-16
+    assert np.abs(u.imag - golden["g1_u_im"]).max() <= 2e-16
+    # docstring example fr.py:131-135 (printed to 8 digits)
+    doc = oracle.angles_to_u((0.2, 0.3, 0.5, 1.5))
+    assert abs(doc[0, 0] - 0.66195018) < 1e-8 and abs(doc[0, 2] - (0.04757188 - 0.6708311j)) < 1e-7
+    assert abs(doc[2, 1] - (-0.64749908 - 0.21213542j)) < 1e-8
+
+
+def test_g2_flavor_angles(golden, oracle):
+    fr = np.array([oracle.angles_to_fr(a) for a in golden["g2_src_angles"]])
+    assert np.abs(fr - golden["g2_fr"]).max() <= 2e-16
+    back = np.array([oracle.fr_to_angles(f) for f in golden["g2_fr_in"]])
+    assert np.abs(back - golden["g2_angles_back"]).max() <= 1e-15
+    # fr.py:97-98
+    assert np.allclose(oracle.angles_to_fr((0.3, 0.4)), golden["ka_angles_to_fr_03_04"], rtol=0, atol=1e-16)
+
+
+def test_g3_u_to_fr_and_docs_known_answers(golden, oracle):
+    U = oracle.angles_to_u(oracle.NUFIT_ANGLES)
+    assert np.abs(U.real - golden["ka_nufit_re"]).max() <= 2e-16
+    out = np.array([oracle.u_to_fr(s, U) for s in golden["g3_src"]])
+    assert np.abs(out - golden["g3_fr_nufit"]).max() <= 2e-16
+    out = np.array([oracle.u_to_fr(s, U) for s in golden["g3_src_raw"]])
+    assert np.abs(out - golden["g3_fr_raw"]).max() <= 2e-16
+    # docs/source/physics.rst:277-279
+    for src, want in (((1, 2, 0), (0.31, 0.35, 0.34)), ((0, 1, 0), (0.18, 0.44, 0.38)), ((1, 0, 0), (0.55, 0.18, 0.27))):
+        got = oracle.u_to_fr(np.array(src) / np.sum(src), U)
+        assert np.abs(got - want).max() < 5e-3
+    # examples/tutorial.ipynb:103-106 NuFIT matrix to 8 digits
+    assert abs(U[0, 0] - 0.82327921) < 1e-8 and abs(U[1, 2] - 0.74336952) < 1e-8
+
+
+@pytest.mark.parametrize("key", ["c1", "c3", "c4", "c5"])
+def test_g4_lnprior(golden, oracle, key):
+    ps = {"c1": notebook_sets(golden)[1], "c3": Cf.unitary_paramset(), "c4": Cf.texture_paramset(6),
+          "c5": Cf.fr_paramsets(6, (0.4, 0.0))[1]}[key]
+    m = oracle.make_model(ps, "PRIOR_ONLY")
+    v = np.array([oracle.lnprior(m, t) for t in golden["g4_%s_theta" % key]])
+    ref = golden["g4_%s_lnprior" % key]
+    assert np.array_equal(np.isinf(v), np.isinf(ref))
+    assert rel_err(v, ref) <= 1e-15
+    assert np.isinf(ref).sum() > 0           # the edge rows really exercise the closed box
+
+
+def test_g4_known_answers(golden, oracle):
+    m = oracle.make_model(notebook_sets(golden)[1], "PRIOR_ONLY")
+    assert oracle.lnprior(m, [0.307, 0.9564, 0.538, 4.08404, 0.9, 0.1]) == pytest.approx(10.781874524028385, rel=1e-15)
+    m = oracle.make_model(Cf.texture_paramset(6), "PRIOR_ONLY")
+    assert oracle.lnprior(m, [0.307, 0.9564, 0.538, 4.08404, 7.4e-23, 2.494e-21, -40]) == pytest.approx(
+        float(golden["ka_c4_lnprior"]), rel=1e-15)
+
+
+def test_g5_multi_gaussian_incl_underflow_band(golden, oracle):
+    v = np.array([oracle.multi_gaussian(p, golden["g5_bf"], 0.02) for p in golden["g5_fr"]])
+    ref = golden["g5_llh"]
+    assert np.isinf(ref).sum() > 100 and ((ref > -1066) & (ref < -1028)).sum() > 100   # wall and band are covered
+    assert np.array_equal(np.isinf(v), np.isinf(ref))
+    assert rel_err(v, ref) == 0.0            # bit-exact, subnormal band included
+    v = np.array([oracle.multi_gaussian(p, golden["g5_bf"], 0.1, 0.0) for p in golden["g5_fr"][:64]])
+    assert rel_err(v, golden["g5_llh_s01_off0"]) <= 1e-15
+
+
+def test_g6_notebook_lnprob(golden, oracle):
+    _, ps = notebook_sets(golden)
+    m = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=golden["g6_bestfit_fr"], smearing=0.02)
+    lp, fr = oracle.lnprob_batch(m, golden["g6_theta"], want_fr=True)
+    assert np.array_equal(np.isinf(lp), np.isinf(golden["g6_lnprob"]))
+    assert rel_err(lp, golden["g6_lnprob"]) <= 1e-15
+    assert np.nanmax(np.abs(fr - golden["g6_fr"])) <= 2e-16
+    # SURVEY Appendix B known answer
+    assert lp[-2] == pytest.approx(-355.3852856116068, rel=1e-14) and lp[-1] == -np.inf
+
+
+def test_g7_params_to_bsmu(golden, oracle):
+    rows = golden["g7_rows"]
+    n_bad = 0
+    for r, ure, uim, ok, ex in zip(rows, golden["g7_u_re"], golden["g7_u_im"], golden["g7_ok"], golden["g7_abs2_exact"]):
+        u, uok = oracle.params_to_BSMu(TEX_ANGLES[int(r[1])], r[2], int(r[0]), r[3])
+        assert bool(ok) == uok                               # same unitarity verdict as the reference
+        if ok:
+            # both are 80-bit evaluations of an ill-conditioned closed form: they agree with each other
+            # to the noise the reference itself shows against the exact value
+            ref_noise = np.abs(ure ** 2 + uim ** 2 - ex).max()
+            assert np.abs(np.abs(u) ** 2 - ex).max() <= max(1e-12, 10 * ref_noise)
+        else:
+            n_bad += 1
+    assert n_bad >= 3
+    u, _ = oracle.params_to_BSMu((0.2, 0.3, 0.5, 1.5), -20, 3, 1000)     # docstring fr.py:354-358
+    assert np.abs(u.real - golden["g7_doc_u_re"]).max() < 1e-15 and np.abs(u.imag - golden["g7_doc_u_im"]).max() < 1e-15
+    m = np.array([oracle.cardano_eqn(a + 1j * b) for a, b in zip(golden["g7_card_h_re"], golden["g7_card_h_im"])])
+    assert np.abs(m.real - golden["g7_card_m_re"]).max() < 1e-15 and np.abs(m.imag - golden["g7_card_m_im"]).max() < 1e-15
+
+
+def test_g8_flux_averaged(golden, oracle):
+    srcs = golden["g8_sources"]
+    worst = 0.0
+    for r, fr, ex, st in zip(golden["g8_rows"], golden["g8_fr"], golden["g8_fr_exact"], golden["g8_status"]):
+        dim, tex, si = int(r[0]), int(r[1]), int(r[2])
+        m = oracle.make_model(Cf.texture_paramset(dim), "BSM_GAUSS", texture=TEX_BY_VALUE[tex].name, dimension=dim,
+                              binning=BIN_EDGES, source_ratio=srcs[si], spectral_index=-2.0)
+        try:
+            f = oracle.flux_averaged_BSMu(m, r[3:])
+            s = 0
+        except AssertionError:
+            s = 2
+        assert s == st
+        if s == 0:
+            worst = max(worst, np.abs(f - fr).max())
+            assert np.abs(f - ex).max() <= 1e-12
+    assert worst <= 1e-12
+    assert (golden["g8_status"] == 2).sum() >= 5
+
+
+def test_g9_lnprob_12dim(golden, oracle):
+    for r, v, st in zip(golden["g9_rows"], golden["g9_lnprob"], golden["g9_status"]):
+        dim, tex = int(r[0]), int(r[1])
+        _, ps = Cf.fr_paramsets(dim, (0.4, 0.0))
+        m = oracle.make_model(ps, "BSM_GAUSS", texture=TEX_BY_VALUE[tex].name, dimension=dim, binning=BIN_EDGES,
+                              source_ratio=r[2:5], bestfit_fr=golden["g9_injected"], smearing=0.02)
+        lp, s = oracle.lnprob_batch(m, r[5:], want_status=True)
+        if st == 2:
+            assert s[0] == 2
+        else:
+            assert s[0] in (0, 1)
+            assert rel_err(lp, [v]) <= 1e-11
