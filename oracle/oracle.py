@@ -88,6 +88,7 @@ def lib():
         L.orc_flux_averaged.restype = C.c_int
         L.orc_log_gauss_mass.argtypes = [C.c_double, C.c_double]
         L.orc_log_gauss_mass.restype = C.c_double
+        L.orc_unitarity_residual_batch.argtypes = [mp, dp, C.c_int64, dp]
         up = C.POINTER(C.c_uint32)
         L.orc_philox_raw.argtypes = [up, up, up]
         L.orc_haar_draw.argtypes = [dp, C.c_uint64, C.c_int64, C.c_int64, dp, dp]
@@ -303,3 +304,11 @@ def haar_draw(source_ratio, seed, n, first=0):
     fr = np.empty((n, 3))
     lib().orc_haar_draw(_dp(_vec(source_ratio, 3)), int(seed), int(first), int(n), _dp(ang), _dp(fr))
     return fr, ang
+
+
+def unitarity_residual_batch(model, theta):
+    """Worst max(|tr|XX^+|-3|, |sum|XX^+|-3|) over the energy bins, per walker (fr.py:489-494)."""
+    th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(-1, model.ndim))
+    out = np.empty(th.shape[0])
+    lib().orc_unitarity_residual_batch(C.byref(model), _dp(th), th.shape[0], _dp(out))
+    return out
