@@ -79,7 +79,7 @@ def cpu_baseline(ps, bf, theta, sample):
     """Time the CPU oracle (checker, never the product) on a bounded sample of the same workload."""
     from oracle import oracle as O
     om = O.make_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # the GPU box grants a 16-core share per GPU
     th1 = theta[:min(len(theta), 200000)]
     t0 = time.perf_counter()
     O.lnprob_batch(om, th1)

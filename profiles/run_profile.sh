@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profile bench.py's kernel on the GPU box (run through gpurun from the repo root):
+#   gpurun -- 'bash profiles/run_profile.sh r01'
+# Pass 1: kernel trace + stats.  Passes 2..4: PMC counters, each in its own run (never combined with
+# trace domains other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit one pass).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/bench_sq2.json 2> $OUT/sq2.err
+find $OUT -name "*.csv" | head -40
+python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
