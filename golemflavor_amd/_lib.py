@@ -40,7 +40,7 @@ class GfModelDesc(C.Structure):
         ("dimension", C.c_int32), ("nbins", C.c_int32),
         ("idx_sm", C.c_int32 * 4), ("idx_mass", C.c_int32 * 2), ("idx_src", C.c_int32 * 2),
         ("idx_scale", C.c_int32), ("idx_mm", C.c_int32 * 4), ("idx_gamma", C.c_int32),
-        ("prior_kind", C.c_int32 * GF_MAX_DIM), ("reserved_", C.c_int32),
+        ("prior_kind", C.c_int32 * GF_MAX_DIM),
         ("lo", C.c_double * GF_MAX_DIM), ("hi", C.c_double * GF_MAX_DIM),
         ("loc", C.c_double * GF_MAX_DIM), ("sigma", C.c_double * GF_MAX_DIM),
         ("log_mass", C.c_double * GF_MAX_DIM),
@@ -58,6 +58,7 @@ SIGNATURES = {
     "gf_abi_version": (C.c_int, []),
     "gf_strerror": (C.c_char_p, [C.c_int]),
     "gf_last_hip_error": (C.c_char_p, []),
+    "gf_sizeof_model_desc": (C.c_size_t, []),
     "gf_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gf_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "gf_model_create": (C.c_int, [C.POINTER(GfModelDesc), C.c_int, C.POINTER(_vp)]),
@@ -107,6 +108,9 @@ def lib():
             fn.argtypes = args
         if L.gf_abi_version() != GF_ABI_VERSION:
             raise GolemHipUnavailable("libgolemhip ABI %d != binding %d" % (L.gf_abi_version(), GF_ABI_VERSION))
+        if L.gf_sizeof_model_desc() != C.sizeof(GfModelDesc):
+            raise GolemHipUnavailable("gf_model_desc layout mismatch: C %d bytes, ctypes %d bytes"
+                                      % (L.gf_sizeof_model_desc(), C.sizeof(GfModelDesc)))
         _lib = L
     return _lib
 

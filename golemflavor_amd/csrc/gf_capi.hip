@@ -154,6 +154,8 @@ const char* gf_strerror(int err)
 
 const char* gf_last_hip_error(void) { return g_err; }
 
+size_t gf_sizeof_model_desc(void) { return sizeof(gf_model_desc); }
+
 int gf_device_count(int* count)
 {
     if (!count) return GF_ERR_INVALID_ARG;

@@ -88,7 +88,6 @@ typedef struct gf_model_desc {
     int32_t idx_mm[4];                 /* NP mixing angles when texture == NONE (fr.py:378)     */
     int32_t idx_gamma;                 /* astroDeltaGamma (llh.py:105); cancels in fr, kept for fidelity */
     int32_t prior_kind[GF_MAX_DIM];    /* gf_prior_kind per column (llh.py:81-90)               */
-    int32_t reserved_;
     double lo[GF_MAX_DIM];             /* Param.ranges[0]  (closed box, llh.py:74-78)           */
     double hi[GF_MAX_DIM];             /* Param.ranges[1]                                       */
     double loc[GF_MAX_DIM];            /* Param.nominal_value (prior centre)                    */
@@ -113,6 +112,7 @@ typedef struct gf_model gf_model;      /* opaque: device constants + stream + st
 int gf_abi_version(void);
 const char* gf_strerror(int err);
 const char* gf_last_hip_error(void);   /* thread-local text of the last failing HIP/RCCL call    */
+size_t gf_sizeof_model_desc(void);     /* sizeof(gf_model_desc) as compiled: lets a binding verify its layout */
 int gf_device_count(int* count);
 int gf_device_name(int device, char* buf, size_t buflen);   /* gcnArchName, e.g. "gfx950:..."   */
 

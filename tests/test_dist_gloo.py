@@ -1,0 +1,95 @@
+"""CPU: the N > 1 path on gloo, world_size 2 -- sharding, descriptor broadcast, gather of chains."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from golemflavor_amd import dist as gdist
+
+
+def test_shard_partition_is_exact():
+    for n in (0, 1, 7, 64, 256):
+        for world in (1, 2, 3, 8):
+            seen = sorted(g for r in range(world) for g in gdist.shard(n, r, world))
+            assert seen == list(range(n))
+            assert max([len(gdist.shard(n, r, world)) for r in range(world)] + [0]) == gdist.slots_per_rank(n, world)
+    with pytest.raises(ValueError):
+        gdist.shard(4, 2, 2)
+
+
+def test_local_backend_roundtrip():
+    b = gdist.LocalBackend()
+    chains = gdist.run_grid([0.1, 0.2, 0.3], lambda p, g: np.full((4, 2), p + g), b)
+    assert len(chains) == 3 and np.all(chains[2] == 2.3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    from golemflavor_amd import configs as Cf
+    from golemflavor_amd import dist as gd
+    from golemflavor_amd import mcmc as mcmc_utils
+    from golemflavor_amd.descriptor import compile_model
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = gd.GlooBackend()
+    # 1) broadcast of the packed descriptors ("fixed physics constants") from rank 0
+    descs = []
+    if rank == 0:
+        descs = [compile_model(Cf.texture_paramset(6), "PRIOR_ONLY", scale_fixed=-40.0 - k) for k in range(5)]
+    got = gd.broadcast_descriptors(descs, b)
+    assert len(got) == 5 and [d.scale_fixed for d in got] == [-40.0 - k for k in range(5)] and got[3].ndim == 7
+    # 2) independent chains: grid point g -> rank g mod world, seeded per grid point
+    points = [(-1.0 + 0.5 * g, 0.3 + 0.1 * g) for g in range(5)]
+
+    def run_chain(point, g):
+        mu, sig = point
+
+        class F:
+            vectorized = True
+
+            def __call__(self, th):
+                return -0.5 * np.sum(((np.atleast_2d(th) - mu) / sig) ** 2, axis=1)
+        s = mcmc_utils.EnsembleSampler(8, 2, F(), seed=100 + g)
+        s.run_mcmc(np.random.default_rng(g).normal(mu, sig, size=(8, 2)), 30)
+        return s.flatchain
+
+    chains = gd.run_grid(points, run_chain, b)
+    np.save(os.path.join(tmpdir, "chains_rank%d.npy" % rank), np.stack(chains))
+    b.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "chains_rank0.npy")
+    b = np.load(tmp_path / "chains_rank1.npy")
+    assert a.shape == (5, 8 * 30, 2) and np.array_equal(a, b)          # every rank holds every chain
+    # identical to a single-process run of the same seeded chains
+    from golemflavor_amd import mcmc as mcmc_utils
+    for g in range(5):
+        mu, sig = -1.0 + 0.5 * g, 0.3 + 0.1 * g
+
+        class F:
+            vectorized = True
+
+            def __call__(self, th):
+                return -0.5 * np.sum(((np.atleast_2d(th) - mu) / sig) ** 2, axis=1)
+        s = mcmc_utils.EnsembleSampler(8, 2, F(), seed=100 + g)
+        s.run_mcmc(np.random.default_rng(g).normal(mu, sig, size=(8, 2)), 30)
+        assert np.array_equal(a[g], s.flatchain)

@@ -1,0 +1,86 @@
+"""GPU: the emcee-driven call surface end to end (BASELINE config 1 plumbing) and the RCCL binding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import BIN_EDGES, bsm_args, notebook_sets
+from golemflavor_amd import _lib
+from golemflavor_amd import configs as Cf
+from golemflavor_amd import dist as gdist
+from golemflavor_amd import llh as llh_utils
+from golemflavor_amd import mcmc as mcmc_utils
+from golemflavor_amd.enums import Texture
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lnprob_callable_keeps_reference_conventions(golden):
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    v = f([0.307, 0.9564, 0.538, 4.08404, 0.9, 0.1])
+    assert isinstance(v, float) and v == pytest.approx(-355.3852856116068, rel=1e-12)
+    assert f([1.2, 0.9564, 0.538, 4.08404, 0.9, 0.1]) == -np.inf
+    with pytest.raises(AssertionError):
+        f([0.3, 0.9, 0.5])
+    out = f(golden["g6_theta"][:10])
+    assert out.shape == (10,) and np.allclose(out, golden["g6_lnprob"][:10], rtol=1e-12)
+    assert llh_utils.lnprior([0.307, 0.9564, 0.538, 4.08404, 0.9, 0.1], ps) == pytest.approx(10.781874524028385, rel=1e-13)
+    f.close()
+
+
+def test_config1_notebook_chain_through_mcmc(golden, capsys):
+    """100 walkers x 6 dims through mcmc.mcmc(): one launch per half-ensemble; acceptance fraction and
+    posterior in line with the reference notebook (mean acceptance 0.427, examples/inference.ipynb:429-438)."""
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    np.random.seed(26)
+    p0 = mcmc_utils.flat_seed(ps, nwalkers=100)
+    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1200, threads=1)
+    out = capsys.readouterr().out
+    assert samples.shape == (100 * 1200, 6)
+    assert f.ncalls == 2 + 2 * 1600 and f.nevals == 200 + 100 * 1600
+    acc = float(out.split("sum of acceptance fraction")[1].split()[0]) / 100
+    assert 0.36 < acc < 0.50
+    # the three mixing parameters are prior-dominated (sigma 0.013, 0.00147, 0.069 around the nominal values)
+    assert samples[:, 0].mean() == pytest.approx(0.307, abs=0.003) and samples[:, 0].std() == pytest.approx(0.013, rel=0.2)
+    assert samples[:, 1].mean() == pytest.approx((1 - 0.02206) ** 2, abs=0.0005)
+    # injected source (1,0,0): the source composition posterior prefers electron-rich sources
+    src = samples[:, 4:6]
+    fe = np.sqrt(src[:, 0]) * (1 + src[:, 1]) / 2
+    assert fe.mean() > 0.6
+    f.close()
+
+
+def test_bsm_callable_raises_on_nonunitary_like_reference():
+    asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))      # fr_to_angles((1,1,1))
+    args = bsm_args(6, Texture.OEU, (1 / 3, 2 / 3, 0))
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.02)
+    th = np.array([0.307, 0.9564, 0.538, 4.08404, 7.4e-23, 2.494e-21, 1.0, 0.5, 1.0, 6.9, 2.5, -50.0])
+    v = f(th)
+    assert np.isfinite(v) or v == -np.inf
+    th_bad = th.copy()
+    th_bad[11] = -30.0                                             # the reference raises here
+    with pytest.raises(AssertionError, match="not unitary"):
+        f(th_bad)
+    g = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.02, on_nonunitary="-inf")
+    assert g(th_bad) == -np.inf
+    f.close()
+    g.close()
+
+
+def test_rccl_binding_world_size_1():
+    """The gf_comm_* entry points on a single rank: create, broadcast, all-gather, barrier."""
+    b = gdist.RcclBackend(rank=0, world=1, device=0)
+    payload = bytes(range(256)) * 5
+    assert b.broadcast_bytes(payload, 0) == payload
+    from golemflavor_amd.descriptor import compile_model
+    from golemflavor_amd.model import Model
+    with Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY")) as m:
+        x = np.arange(1000, dtype=np.float64).reshape(250, 4)
+        got = b.allgather(x, m)
+        assert got.shape == (1, 250, 4) and np.array_equal(got[0], x)
+        chains = gdist.gather_chains({0: x, 1: x + 1}, 2, b, allgather=lambda a: b.allgather(a, m))
+        assert np.array_equal(chains[1], x + 1)
+    b.barrier()
+    b.close()
