@@ -63,6 +63,7 @@ struct gf_model {
     GfCommon c;
     GfBsm hb;
     GfBsm* d_bsm = nullptr;
+    double* d_ptab = nullptr;    // [GF_MAX_DIM][4] = {lo, hi, loc, 1/sigma}: the kernels' LDS constant table
     hipStream_t stream = nullptr;
     int device = 0;
     int cus = 256;
@@ -115,7 +116,7 @@ int launch_lnprob(gf_model* m, const double* d_theta, int layout, int64_t n, dou
     if (m->c.mode == GF_MODE_BSM_GAUSS)
         e = gf_launch_bsm(m->c, m->d_bsm, m->hb, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, m->stream);
     else
-        e = gf_launch_lnprob_sm(m->c, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, m->stream);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
     return GF_OK;
 }
@@ -300,6 +301,14 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
     m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        double tab[GF_MAX_DIM * 4];
+        for (int i = 0; i < GF_MAX_DIM; ++i) {
+            tab[4 * i] = c.lo[i]; tab[4 * i + 1] = c.hi[i]; tab[4 * i + 2] = c.loc[i]; tab[4 * i + 3] = c.inv_sigma[i];
+        }
+        e = hipMalloc((void**)&m->d_ptab, sizeof(tab));
+        if (e == hipSuccess) e = hipMemcpy(m->d_ptab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && d->mode == GF_MODE_BSM_GAUSS) {
         e = hipMalloc((void**)&m->d_bsm, sizeof(GfBsm));
         if (e == hipSuccess) e = hipMemcpy(m->d_bsm, &m->hb, sizeof(GfBsm), hipMemcpyHostToDevice);
@@ -319,6 +328,7 @@ void gf_model_destroy(gf_model* m)
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->d_bsm) (void)hipFree(m->d_bsm);
+    if (m->d_ptab) (void)hipFree(m->d_ptab);
     if (m->d_theta) (void)hipFree(m->d_theta);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_status) (void)hipFree(m->d_status);

@@ -19,6 +19,75 @@ __device__ __forceinline__ double gf_inf() { return __longlong_as_double(0x7ff00
 __device__ __forceinline__ double gf_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
 // ---------------------------------------------------------------------------------------------
+// fp64 building blocks.  The compiler's sqrt()/division/cos() lower to IEEE-complete sequences
+// (input scaling for denormals, class fix-ups, Payne-Hanek argument reduction) that cost 2x the
+// instructions this path needs; the forms below keep <= 1 ulp on the domain the physics feeds them and
+// return NaN outside it.  Parity is checked end to end against the long-double oracle (1e-10 bar,
+// ~1e-15 observed).
+
+// sqrt for x in [0, ~1e300): v_rsq_f64 seed + two Newton-Raphson (Goldschmidt) refinements, no denormal
+// scaling.  x == 0 -> 0; x < 0 or NaN -> NaN.
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+// 1/x for finite normal x: v_rcp_f64 seed + two Newton-Raphson steps.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// sin and cos of x, |x| < 2^20 * pi/2: three-step Cody-Waite reduction with FMA (33-bit pieces of pi/2,
+// the published fdlibm split), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error
+// <= ~2e-16.  Larger |x| (never a physical phase) take the library path.
+__device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs)
+{
+    if (!(fabs(x) < 1.6e6)) { *sn = gf_nan(); *cs = gf_nan(); return; }   // TEMP
+    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
+    double r = fma(-fn, 1.57079632673412561417e+00, x);              // pio2_1 (33 bits)
+    r = fma(-fn, 6.07710050630396597660e-11, r);                     // pio2_2 (33 bits)
+    r = fma(-fn, 2.02226624879595063154e-21, r);                     // pio2_2t: the rest of pi/2
+    const int q = (int)fn;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    // quadrant: (sin, cos)(x) = (s, c), (c, -s), (-s, -c), (-c, s) for q mod 4 = 0, 1, 2, 3
+    const double ss = (q & 1) ? c : s;
+    const double cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ double fast_cos(double x)
+{
+    double s, c;
+    fast_sincos(x, &s, &c);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).
 // AoS: the block is contiguous in memory -> 16-B vector loads, lane-contiguous.
 // SoA: each lane loads its own ndim values (8-B, lane-contiguous per column).
@@ -93,13 +162,13 @@ __device__ __forceinline__ bool lnprior(const GfCommon& c, const double* row, do
 // reference takes the angles in [0, pi/2] via asin/acos of a square root, fr.py:145-147).
 __device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23_2, double dcp, double p[3][3])
 {
-    const double c13_2 = sqrt(c13_4);
+    const double c13_2 = fast_sqrt(c13_4);
     const double s13_2 = 1.0 - c13_2;
     const double c12_2 = 1.0 - s12_2;
     const double c23_2 = 1.0 - s23_2;
     const double a = s12_2 * c23_2, b = c12_2 * s23_2;
     const double e = c12_2 * c23_2, f = s12_2 * s23_2;
-    const double j2 = 2.0 * sqrt((a * b) * s13_2) * cos(dcp);
+    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos(dcp);
     p[0][0] = c12_2 * c13_2;
     p[0][1] = s12_2 * c13_2;
     p[0][2] = s13_2;
@@ -115,7 +184,7 @@ __device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23
 // (1-c)/2 exactly, so no trigonometry is needed.
 __device__ __forceinline__ void angles_to_fr(double sphi4, double c2psi, double f[3])
 {
-    const double sphi2 = sqrt(sphi4);
+    const double sphi2 = fast_sqrt(sphi4);
     const double spsi2 = 0.5 * (1.0 - c2psi);
     const double cpsi2 = 1.0 - spsi2;
     f[0] = fabs(sphi2 * cpsi2);
@@ -133,7 +202,7 @@ __device__ __forceinline__ void propagate(const double p[3][3], const double src
     const double p01 = fma(p[0][2], p[1][2], fma(p[0][1], p[1][1], p[0][0] * p[1][0]));
     const double p02 = fma(p[0][2], p[2][2], fma(p[0][1], p[2][1], p[0][0] * p[2][0]));
     const double p12 = fma(p[1][2], p[2][2], fma(p[1][1], p[2][1], p[1][0] * p[2][0]));
-    const double inv = 1.0 / src_sum;
+    const double inv = fast_rcp(src_sum);
     out[0] = fma(p02, src[2], fma(p01, src[1], p00 * src[0])) * inv;
     out[1] = fma(p12, src[2], fma(p11, src[1], p01 * src[0])) * inv;
     out[2] = fma(p22, src[2], fma(p12, src[1], p02 * src[0])) * inv;
@@ -143,15 +212,22 @@ __device__ __forceinline__ void propagate(const double p[3][3], const double src
 // logpdf = -0.5 (3 log 2pi + log_pdet + maha) and then exp(); the reference takes log() of that, so
 // below the fp64 underflow wall the value is quantised (subnormal band, logpdf in (-745.13, -708.40))
 // or -inf.  Emulated: y = exp(logpdf) / 2^-1074 rounded to an integer count of subnormal ulps.
-__device__ __forceinline__ double log_of_exp(double x)
+// Cold path, deliberately not inlined: exp()/log() bring ~25 fp64 literals whose materialisation the
+// compiler would otherwise hoist out of the tile loop and keep live in (scarce) scalar registers.
+__device__ __attribute__((noinline)) double log_of_exp_band(double x)
 {
-    if (x >= -708.3964185322641) return x;              // exp(x) is a normal number: log(exp(x)) == x to 1 ulp
     const double HI = 744.4400719213812, LO = 4.422444340918698e-14;   // 1074 ln 2 = HI + LO
     const double t = x + HI;                            // exact (both multiples of 2^-43, |t| < 64)
     const double y = exp(t) * (1.0 + LO);
     const double k = rint(y);
     if (!(k >= 1.0)) return (x != x) ? x : -gf_inf();   // underflows to zero -> log(0) = -inf
     return (log(k) - HI) - LO;
+}
+
+__device__ __forceinline__ double log_of_exp(double x)
+{
+    if (x >= -708.3964185322641) return x;              // exp(x) is a normal number: log(exp(x)) == x to 1 ulp
+    return log_of_exp_band(x);
 }
 
 __device__ __forceinline__ double gauss_llh(const GfCommon& c, const double fr[3])

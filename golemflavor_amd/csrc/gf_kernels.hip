@@ -25,44 +25,138 @@ using namespace gfdev;
 // ---------------------------------------------------------------------------------------------
 // lnprob for MODE_PRIOR_ONLY and MODE_SM_GAUSS.  One lane per walker, grid-stride over 64-walker
 // wave tiles.
+//
+// Per-column prior constants {lo, hi, loc, 1/sigma} come from a 512-B LDS table (ds_read_b128
+// broadcasts) rather than from kernel-argument SGPRs: with them in SGPRs the kernel needed > 102 scalar
+// registers and spilled to VGPR lanes (52 v_readlane per tile in the first version, profiles/r01/a_*).
+// AoS tiles are software-pipelined: the 16-B loads of the wave's next tile are issued before the
+// current tile is evaluated, so a wave's HBM latency hides under its own fp64 work.
+
+// one walker: box + priors from the LDS constant table, then the mode's likelihood
 template <int NDIM, int MODE>
-__global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm(const GfCommon c, const double* __restrict__ theta,
-                                                         int layout, int64_t n, double* __restrict__ lnprob,
-                                                         double* __restrict__ fr_out, int32_t* __restrict__ status)
+__device__ __forceinline__ void eval_walker(const GfCommon& c, const double* ctab, const double* row, int ndim_rt,
+                                            double& val, double fr[3], int& st)
 {
-    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
+    const int ndim = NDIM ? NDIM : ndim_rt;
+    bool inbox = true;
+    double acc = 0.0;
+#pragma unroll
+    for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double x = row[d];
+        const double2 lh = *reinterpret_cast<const double2*>(ctab + 4 * d);       // lo, hi
+        const double2 ls = *reinterpret_cast<const double2*>(ctab + 4 * d + 2);   // loc, 1/sigma
+        inbox = inbox && (x >= lh.x) && (x <= lh.y);                               // llh.py:74-78 (NaN fails)
+        const double z = (x - ls.x) * ls.y;
+        acc = fma(-0.5 * z, z, acc);                                               // llh.py:81-90
+    }
+    const double lp = acc + c.prior_const;
+    fr[0] = fr[1] = fr[2] = gf_nan();
+    st = ST_OK;
+    if (!inbox) {
+        val = -gf_inf();                                 // llh.py:78 / ipynb:360-361
+        st = ST_OUT_OF_PRIOR;
+    } else if (MODE == MODE_PRIOR_ONLY) {
+        val = lp + c.flat_llh;                           // mc_unitary.py:131,139
+    } else {
+        sm_composition(c, row, fr);
+        val = lp + gauss_llh(c, fr);                     // ipynb:364
+        if (val != val) st = ST_NAN;
+    }
+}
+
+// Hot kernel: AoS theta, compile-time row length, FULL 64-walker tiles only (the launcher hands the
+// ragged remainder to k_lnprob_sm_gen).  Keeping the generic staging out of this loop keeps its
+// induction variables and bounds checks out of the register budget.
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_fast(const GfCommon c, const double* __restrict__ ptab,
+                                                              const double* __restrict__ theta, int64_t nfull,
+                                                              double* __restrict__ lnprob, double* __restrict__ fr_out,
+                                                              int32_t* __restrict__ status)
+{
+    static_assert(NDIM > 0, "fast path needs a compile-time row length");
+    constexpr int NV = GF_WAVE * NDIM / 2;                     // 16-B vectors in a tile
+    constexpr int VPL = (NV + GF_WAVE - 1) / GF_WAVE;          // ... per lane
+    constexpr bool EVEN = (NV % GF_WAVE) == 0;
+    typedef double d2_t __attribute__((ext_vector_type(2)));   // native vector: stays in registers
+    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * NDIM];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4];
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / GF_WAVE);        // wave-uniform -> SALU
+    double* tile = tiles[wave];
+    const int stride = gridDim.x * GF_WAVES_PER_BLOCK;
+    int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave;
+    if (t >= nfull) return;
+
+    d2_t pre[VPL];
+    {
+        const d2_t* src = reinterpret_cast<const d2_t*>(theta + t * (GF_WAVE * NDIM));
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            if (EVEN || j * GF_WAVE + lane < NV) pre[j] = src[j * GF_WAVE + lane];
+    }
+    for (; t < nfull; t += stride) {
+        // current tile: registers -> LDS; next tile of this wave: HBM -> registers, in flight while the
+        // current one is evaluated.  The last iteration re-fetches its own tile (one redundant tile per
+        // wave per launch, cheaper than a divergent pipeline tail).
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            if (EVEN || j * GF_WAVE + lane < NV) reinterpret_cast<d2_t*>(tile)[j * GF_WAVE + lane] = pre[j];
+        const int64_t tn = (t + stride < nfull) ? t + stride : t;
+        const d2_t* src = reinterpret_cast<const d2_t*>(theta + tn * (GF_WAVE * NDIM));
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            if (EVEN || j * GF_WAVE + lane < NV) pre[j] = src[j * GF_WAVE + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int64_t i = t * GF_WAVE + lane;
+        double val, fr[3];
+        int st;
+        eval_walker<NDIM, MODE>(c, ctab, tile + lane * NDIM, NDIM, val, fr, st);
+        lnprob[i] = val;
+        if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
+        if (status) status[i] = st;
+        // the tile is rewritten by the same wave next iteration; keep its reads ahead of those writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Generic kernel: any layout, runtime row length, ragged tiles; walkers [first, n) of the batch.
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_gen(const GfCommon c, const double* __restrict__ ptab,
+                                                             const double* __restrict__ theta, int layout, int64_t first,
+                                                             int64_t n, double* __restrict__ lnprob,
+                                                             double* __restrict__ fr_out, int32_t* __restrict__ status)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * ND];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4];
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int wave = threadIdx.x / GF_WAVE;
     const int ndim = NDIM ? NDIM : c.ndim;
     double* tile = tiles[wave];
-    const int64_t ntiles = (n + GF_WAVE - 1) / GF_WAVE;
+    const int64_t ntiles = (n - first + GF_WAVE - 1) / GF_WAVE;
     const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
-        const int64_t w0 = t * GF_WAVE;
+        const int64_t w0 = first + t * GF_WAVE;
         stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane);
         const int64_t i = w0 + lane;
         if (i < n) {
-            const double* row = tile + lane * ndim;
-            double lp;
-            const bool inbox = lnprior<NDIM>(c, row, lp);
-            double fr[3] = {gf_nan(), gf_nan(), gf_nan()};
-            double val;
-            int st = ST_OK;
-            if (!inbox) {
-                val = -gf_inf();                         // llh.py:78 / ipynb:360-361
-                st = ST_OUT_OF_PRIOR;
-            } else if (MODE == MODE_PRIOR_ONLY) {
-                val = lp + c.flat_llh;                   // mc_unitary.py:131,139
-            } else {
-                sm_composition(c, row, fr);
-                val = lp + gauss_llh(c, fr);             // ipynb:364
-                if (val != val) st = ST_NAN;
-            }
+            double val, fr[3];
+            int st;
+            eval_walker<NDIM, MODE>(c, ctab, tile + lane * ndim, ndim, val, fr, st);
             lnprob[i] = val;
             if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
             if (status) status[i] = st;
         }
-        // the tile is rewritten by the same wave next iteration; keep its reads ahead of those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -158,16 +252,35 @@ inline int grid_for(int64_t work_items, int per_block, int cus)
     return (int)blocks;
 }
 
-template <int NDIM>
-hipError_t launch_lnprob_sm_n(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
-                              double* fr, int32_t* status, int cus, hipStream_t s)
+template <int NDIM, int MODE>
+hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const double* theta, int layout, int64_t n,
+                               double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
-    const int grid = grid_for(n, GF_BLOCK, cus);
-    if (c.mode == MODE_PRIOR_ONLY)
-        hipLaunchKernelGGL((k_lnprob_sm<NDIM, MODE_PRIOR_ONLY>), dim3(grid), dim3(GF_BLOCK), 0, s, c, theta, layout, n, lnprob, fr, status);
-    else
-        hipLaunchKernelGGL((k_lnprob_sm<NDIM, MODE_SM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, s, c, theta, layout, n, lnprob, fr, status);
+    int64_t first = 0;
+    if constexpr (NDIM != 0) {
+        const int64_t nfull = n / GF_WAVE;
+        if (layout == 0 && nfull > 0) {
+            const int grid = grid_for(nfull * GF_WAVE, GF_BLOCK, cus);
+            hipLaunchKernelGGL((k_lnprob_sm_fast<NDIM, MODE>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull,
+                               lnprob, fr, status);
+            first = nfull * GF_WAVE;
+        }
+    }
+    if (first < n) {
+        const int grid = grid_for(n - first, GF_BLOCK, cus);
+        hipLaunchKernelGGL((k_lnprob_sm_gen<NDIM, MODE>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, layout, first, n,
+                           lnprob, fr, status);
+    }
     return hipGetLastError();
+}
+
+template <int NDIM>
+hipError_t launch_lnprob_sm_n(const GfCommon& c, const double* ptab, const double* theta, int layout, int64_t n,
+                              double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+{
+    if (c.mode == MODE_PRIOR_ONLY)
+        return launch_lnprob_sm_nm<NDIM, MODE_PRIOR_ONLY>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
+    return launch_lnprob_sm_nm<NDIM, MODE_SM_GAUSS>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
 }
 
 template <int NDIM>
@@ -181,15 +294,15 @@ hipError_t launch_propagate_sm_n(const GfCommon& c, const double* theta, int lay
 
 }  // namespace
 
-hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
-                               double* fr, int32_t* status, int cus, hipStream_t s)
+hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* ptab, const double* theta, int layout, int64_t n,
+                               double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 4: return launch_lnprob_sm_n<4>(c, theta, layout, n, lnprob, fr, status, cus, s);
-    case 6: return launch_lnprob_sm_n<6>(c, theta, layout, n, lnprob, fr, status, cus, s);
-    case 7: return launch_lnprob_sm_n<7>(c, theta, layout, n, lnprob, fr, status, cus, s);
-    case 12: return launch_lnprob_sm_n<12>(c, theta, layout, n, lnprob, fr, status, cus, s);
-    default: return launch_lnprob_sm_n<0>(c, theta, layout, n, lnprob, fr, status, cus, s);
+    case 4: return launch_lnprob_sm_n<4>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
+    case 6: return launch_lnprob_sm_n<6>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
+    case 7: return launch_lnprob_sm_n<7>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
+    case 12: return launch_lnprob_sm_n<12>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
+    default: return launch_lnprob_sm_n<0>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
     }
 }
 

@@ -6,8 +6,9 @@
 
 #include "gf_consts.h"
 
-hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* lnprob,
-                               double* fr, int32_t* status, int cus, hipStream_t s);
+// `ptab`: device table [GF_MAX_DIM][4] = {lo, hi, loc, 1/sigma} per column (GfModel::d_ptab)
+hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* ptab, const double* theta, int layout, int64_t n,
+                               double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s);
 hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* fr,
                                   int32_t* status, int cus, hipStream_t s);
 hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,
