@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgolemhip.so")
+LIB_PATH = os.environ.get("GOLEMHIP_LIB") or os.path.join(HERE, "libgolemhip.so")   # override: kernel A/B experiments
 
 GF_ABI_VERSION = 1
 GF_MAX_DIM = 16

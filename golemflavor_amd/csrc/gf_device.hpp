@@ -224,20 +224,22 @@ __device__ __attribute__((noinline)) double log_of_exp_band(double x)
     return (log(k) - HI) - LO;
 }
 
-__device__ __forceinline__ double log_of_exp(double x)
+__device__ __forceinline__ double log_of_exp(double x, bool live = true)
 {
-    if (x >= -708.3964185322641) return x;              // exp(x) is a normal number: log(exp(x)) == x to 1 ulp
+    // exp(x) is a normal number above the threshold: log(exp(x)) == x to 1 ulp.  `live` = false lanes
+    // (walkers already rejected by the box prior) never take the cold path.
+    if (!live || x >= -708.3964185322641) return x;
     return log_of_exp_band(x);
 }
 
-__device__ __forceinline__ double gauss_llh(const GfCommon& c, const double fr[3])
+__device__ __forceinline__ double gauss_llh(const GfCommon& c, const double fr[3], bool live = true)
 {
     const double d0 = (fr[0] - c.bf[0]) * c.inv_smear;
     const double d1 = (fr[1] - c.bf[1]) * c.inv_smear;
     const double d2 = (fr[2] - c.bf[2]) * c.inv_smear;
     const double maha = fma(d2, d2, fma(d1, d1, d0 * d0));
     const double logpdf = -0.5 * (c.gauss_c0 + maha);
-    return log_of_exp(logpdf) + c.offset;
+    return log_of_exp(logpdf, live) + c.offset;
 }
 
 __device__ __forceinline__ double pick(const double* row, int idx, double fixed)

@@ -32,8 +32,12 @@ using namespace gfdev;
 // AoS tiles are software-pipelined: the 16-B loads of the wave's next tile are issued before the
 // current tile is evaluated, so a wave's HBM latency hides under its own fp64 work.
 
-// one walker: box + priors from the LDS constant table, then the mode's likelihood
-template <int NDIM, int MODE>
+// one walker: box + priors from the LDS constant table, then the mode's likelihood.  Branch-free: the
+// likelihood of an out-of-box walker is computed and discarded (a wave runs it anyway if any lane is
+// inside), which keeps the LDS reads and the fp64 chain in one straight-line block.
+// SAMPLED = every mixing parameter and both source angles are columns of theta (the notebook posterior):
+// drops the fixed-value selects and their scalar constants.
+template <int NDIM, int MODE, bool SAMPLED, bool WANT_FR>
 __device__ __forceinline__ void eval_walker(const GfCommon& c, const double* ctab, const double* row, int ndim_rt,
                                             double& val, double fr[3], int& st)
 {
@@ -46,30 +50,52 @@ __device__ __forceinline__ void eval_walker(const GfCommon& c, const double* cta
         const double x = row[d];
         const double2 lh = *reinterpret_cast<const double2*>(ctab + 4 * d);       // lo, hi
         const double2 ls = *reinterpret_cast<const double2*>(ctab + 4 * d + 2);   // loc, 1/sigma
-        inbox = inbox && (x >= lh.x) && (x <= lh.y);                               // llh.py:74-78 (NaN fails)
+        inbox = inbox & (x >= lh.x) & (x <= lh.y);                                 // llh.py:74-78 (NaN fails)
         const double z = (x - ls.x) * ls.y;
         acc = fma(-0.5 * z, z, acc);                                               // llh.py:81-90
     }
     const double lp = acc + c.prior_const;
-    fr[0] = fr[1] = fr[2] = gf_nan();
-    st = ST_OK;
-    if (!inbox) {
-        val = -gf_inf();                                 // llh.py:78 / ipynb:360-361
-        st = ST_OUT_OF_PRIOR;
-    } else if (MODE == MODE_PRIOR_ONLY) {
-        val = lp + c.flat_llh;                           // mc_unitary.py:131,139
+    double v;
+    if (MODE == MODE_PRIOR_ONLY) {
+        v = lp + c.flat_llh;                             // mc_unitary.py:131,139
+        if (WANT_FR) fr[0] = fr[1] = fr[2] = gf_nan();
     } else {
-        sm_composition(c, row, fr);
-        val = lp + gauss_llh(c, fr);                     // ipynb:364
-        if (val != val) st = ST_NAN;
+        double f[3];
+        if (SAMPLED) {
+            double p[3][3], src[3];
+            pmns_abs2(row[c.idx_sm[0]], row[c.idx_sm[1]], row[c.idx_sm[2]], row[c.idx_sm[3]], p);
+            angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
+            propagate(p, src, (src[0] + src[1]) + src[2], f);
+        } else {
+            sm_composition(c, row, f);
+        }
+        v = lp + gauss_llh(c, f, inbox);                 // ipynb:364
+        if (WANT_FR) {
+            fr[0] = inbox ? f[0] : gf_nan(); fr[1] = inbox ? f[1] : gf_nan(); fr[2] = inbox ? f[2] : gf_nan();
+        }
     }
+    val = inbox ? v : -gf_inf();                         // llh.py:78 / ipynb:360-361
+    st = inbox ? ((v != v) ? ST_NAN : ST_OK) : ST_OUT_OF_PRIOR;
 }
 
 // Hot kernel: AoS theta, compile-time row length, FULL 64-walker tiles only (the launcher hands the
 // ragged remainder to k_lnprob_sm_gen).  Keeping the generic staging out of this loop keeps its
 // induction variables and bounds checks out of the register budget.
-template <int NDIM, int MODE>
-__global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_fast(const GfCommon c, const double* __restrict__ ptab,
+#ifdef GF_NT_LOADS
+#define GF_LOAD_THETA(p) __builtin_nontemporal_load(p)
+#define GF_STORE_OUT(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define GF_LOAD_THETA(p) (*(p))
+#define GF_STORE_OUT(p, v) (*(p) = (v))
+#endif
+#ifndef GF_PREFETCH_DEPTH
+#define GF_PREFETCH_DEPTH 1
+#endif
+#ifndef GF_SM_WAVES_PER_EU
+#define GF_SM_WAVES_PER_EU 4
+#endif
+template <int NDIM, int MODE, bool SAMPLED, bool WANT_FR>
+__global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast(const GfCommon c, const double* __restrict__ ptab,
                                                               const double* __restrict__ theta, int64_t nfull,
                                                               double* __restrict__ lnprob, double* __restrict__ fr_out,
                                                               int32_t* __restrict__ status)
@@ -91,25 +117,33 @@ __global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_fast(const GfCommon c, c
     int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave;
     if (t >= nfull) return;
 
-    d2_t pre[VPL];
-    {
-        const d2_t* src = reinterpret_cast<const d2_t*>(theta + t * (GF_WAVE * NDIM));
+    // PD tiles of this wave are in flight in registers (software pipeline of depth PD); a tile index past
+    // the end is clamped to the wave's last valid tile (a redundant but harmless re-read at the tail).
+    constexpr int PD = GF_PREFETCH_DEPTH;
+    d2_t pre[PD][VPL];
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+        const int64_t tp = (t + (int64_t)p * stride < nfull) ? t + (int64_t)p * stride : t;
+        const d2_t* src = reinterpret_cast<const d2_t*>(theta + tp * (GF_WAVE * NDIM));
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
-            if (EVEN || j * GF_WAVE + lane < NV) pre[j] = src[j * GF_WAVE + lane];
+            if (EVEN || j * GF_WAVE + lane < NV) pre[p][j] = GF_LOAD_THETA(src + j * GF_WAVE + lane);
     }
     for (; t < nfull; t += stride) {
-        // current tile: registers -> LDS; next tile of this wave: HBM -> registers, in flight while the
-        // current one is evaluated.  The last iteration re-fetches its own tile (one redundant tile per
-        // wave per launch, cheaper than a divergent pipeline tail).
+        // oldest tile in flight: registers -> LDS; shift the pipeline; fetch the tile PD strides ahead
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
-            if (EVEN || j * GF_WAVE + lane < NV) reinterpret_cast<d2_t*>(tile)[j * GF_WAVE + lane] = pre[j];
-        const int64_t tn = (t + stride < nfull) ? t + stride : t;
+            if (EVEN || j * GF_WAVE + lane < NV) reinterpret_cast<d2_t*>(tile)[j * GF_WAVE + lane] = pre[0][j];
+#pragma unroll
+        for (int p = 0; p + 1 < PD; ++p)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) pre[p][j] = pre[p + 1][j];
+        const int64_t ta = t + (int64_t)PD * stride;
+        const int64_t tn = (ta < nfull) ? ta : t;
         const d2_t* src = reinterpret_cast<const d2_t*>(theta + tn * (GF_WAVE * NDIM));
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
-            if (EVEN || j * GF_WAVE + lane < NV) pre[j] = src[j * GF_WAVE + lane];
+            if (EVEN || j * GF_WAVE + lane < NV) pre[PD - 1][j] = GF_LOAD_THETA(src + j * GF_WAVE + lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -117,9 +151,9 @@ __global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_fast(const GfCommon c, c
         const int64_t i = t * GF_WAVE + lane;
         double val, fr[3];
         int st;
-        eval_walker<NDIM, MODE>(c, ctab, tile + lane * NDIM, NDIM, val, fr, st);
-        lnprob[i] = val;
-        if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
+        eval_walker<NDIM, MODE, SAMPLED, WANT_FR>(c, ctab, tile + lane * NDIM, NDIM, val, fr, st);
+        GF_STORE_OUT(lnprob + i, val);
+        if (WANT_FR) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
         if (status) status[i] = st;
         // the tile is rewritten by the same wave next iteration; keep its reads ahead of those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -152,7 +186,7 @@ __global__ __launch_bounds__(GF_BLOCK) void k_lnprob_sm_gen(const GfCommon c, co
         if (i < n) {
             double val, fr[3];
             int st;
-            eval_walker<NDIM, MODE>(c, ctab, tile + lane * ndim, ndim, val, fr, st);
+            eval_walker<NDIM, MODE, false, true>(c, ctab, tile + lane * ndim, ndim, val, fr, st);
             lnprob[i] = val;
             if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
             if (status) status[i] = st;
@@ -261,8 +295,12 @@ hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const doub
         const int64_t nfull = n / GF_WAVE;
         if (layout == 0 && nfull > 0) {
             const int grid = grid_for(nfull * GF_WAVE, GF_BLOCK, cus);
-            hipLaunchKernelGGL((k_lnprob_sm_fast<NDIM, MODE>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull,
-                               lnprob, fr, status);
+            const bool sampled = c.idx_sm[0] >= 0 && c.idx_sm[1] >= 0 && c.idx_sm[2] >= 0 && c.idx_sm[3] >= 0 &&
+                                 c.idx_src[0] >= 0 && c.idx_src[1] >= 0;
+#define GF_GO(S, F) hipLaunchKernelGGL((k_lnprob_sm_fast<NDIM, MODE, S, F>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull, lnprob, fr, status)
+            if (sampled) { if (fr) GF_GO(true, true); else GF_GO(true, false); }
+            else         { if (fr) GF_GO(false, true); else GF_GO(false, false); }
+#undef GF_GO
             first = nfull * GF_WAVE;
         }
     }
