@@ -242,6 +242,8 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         const double s = std::pow(d->smearing, 2);
         c.inv_smear = std::sqrt(1.0 / s);
         c.gauss_c0 = 3.0 * std::log(2.0 * M_PI) + ((std::log(s) + std::log(s)) + std::log(s));
+        c.gauss_mh = -0.5 * (c.inv_smear * c.inv_smear);
+        c.gauss_k = -0.5 * c.gauss_c0;
     }
     c.offset = d->offset;
     c.flat_llh = d->flat_llh;

@@ -32,6 +32,8 @@ struct GfCommon {
     double bf[3];
     double inv_smear;               // sqrt(1 / smearing^2)      (scipy _PSD: U = u * sqrt(1/s))
     double gauss_c0;                // 3 log(2 pi) + log_pdet
+    double gauss_mh;                // -0.5 * inv_smear^2
+    double gauss_k;                 // -0.5 * gauss_c0
     double offset;
     double flat_llh;
 };

@@ -87,6 +87,29 @@ __device__ __forceinline__ double fast_cos(double x)
     return c;
 }
 
+// Cold, out-of-line general cosine (keeps its literals out of the hot loop's register budget).
+__device__ __attribute__((noinline)) double cos_general(double x) { return fast_cos(x); }
+
+// cos(x) for a CP phase.  Every paramset of the reference boxes dcp into [0, 2 pi]
+// (scripts/fr.py:41, examples/inference.ipynb:253), so the fast path folds that interval onto
+// u = |x - pi| - pi/2 in [-pi/2, pi/2] where cos x = sin u, and evaluates one odd minimax polynomial
+// (9 terms, fitted in 50-digit arithmetic: approximation error 3e-19, end-to-end abs error <= 2.8e-16).
+// Any other x takes cos_general.
+__device__ __forceinline__ double fast_cos_phase(double x)
+{
+    const double u = fabs(x - 3.141592653589793) - 1.5707963267948966;
+    if (!(fabs(u) <= 1.5707963277948966)) return cos_general(x);     // pi/2 + 1e-9; NaN goes here too
+    const double z = u * u;
+    double q = fma(z, 2.7117413873509064e-15, -7.641995277350052e-13);
+    q = fma(z, q, 1.605889634387573e-10);
+    q = fma(z, q, -2.505210587009456e-08);
+    q = fma(z, q, 2.75573191979119e-06);
+    q = fma(z, q, -0.00019841269841110079);
+    q = fma(z, q, 0.008333333333332799);
+    q = fma(z, q, -0.16666666666666657);
+    return fma(u * z, q, u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).
 // AoS: the block is contiguous in memory -> 16-B vector loads, lane-contiguous.
@@ -168,7 +191,7 @@ __device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23
     const double c23_2 = 1.0 - s23_2;
     const double a = s12_2 * c23_2, b = c12_2 * s23_2;
     const double e = c12_2 * c23_2, f = s12_2 * s23_2;
-    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos(dcp);
+    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos_phase(dcp);
     p[0][0] = c12_2 * c13_2;
     p[0][1] = s12_2 * c13_2;
     p[0][2] = s13_2;
@@ -192,20 +215,19 @@ __device__ __forceinline__ void angles_to_fr(double sphi4, double c2psi, double 
     f[2] = fabs(1.0 - sphi2);
 }
 
-// golemflavor/fr.py:502-536 u_to_fr: out_b = sum_a sum_i |U_ai|^2 |U_bi|^2 src_a / sum(src)
+// golemflavor/fr.py:502-536 u_to_fr: out_b = sum_a sum_i |U_ai|^2 |U_bi|^2 src_a / sum(src).
+// Evaluated as two 3x3 matrix-vector products, w_i = sum_a |U_ai|^2 src_a / sum(src) and
+// out_b = sum_i |U_bi|^2 w_i (18 FMAs), instead of forming P = |U|^2 |U|^2^T (27).
 __device__ __forceinline__ void propagate(const double p[3][3], const double src[3], double src_sum, double out[3])
 {
-    // P_ab = sum_i p[a][i] p[b][i] is symmetric: six dot products
-    const double p00 = fma(p[0][2], p[0][2], fma(p[0][1], p[0][1], p[0][0] * p[0][0]));
-    const double p11 = fma(p[1][2], p[1][2], fma(p[1][1], p[1][1], p[1][0] * p[1][0]));
-    const double p22 = fma(p[2][2], p[2][2], fma(p[2][1], p[2][1], p[2][0] * p[2][0]));
-    const double p01 = fma(p[0][2], p[1][2], fma(p[0][1], p[1][1], p[0][0] * p[1][0]));
-    const double p02 = fma(p[0][2], p[2][2], fma(p[0][1], p[2][1], p[0][0] * p[2][0]));
-    const double p12 = fma(p[1][2], p[2][2], fma(p[1][1], p[2][1], p[1][0] * p[2][0]));
     const double inv = fast_rcp(src_sum);
-    out[0] = fma(p02, src[2], fma(p01, src[1], p00 * src[0])) * inv;
-    out[1] = fma(p12, src[2], fma(p11, src[1], p01 * src[0])) * inv;
-    out[2] = fma(p22, src[2], fma(p12, src[1], p02 * src[0])) * inv;
+    const double s0 = src[0] * inv, s1 = src[1] * inv, s2 = src[2] * inv;
+    const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
+    const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
+    const double w2 = fma(p[2][2], s2, fma(p[1][2], s1, p[0][2] * s0));
+    out[0] = fma(p[0][2], w2, fma(p[0][1], w1, p[0][0] * w0));
+    out[1] = fma(p[1][2], w2, fma(p[1][1], w1, p[1][0] * w0));
+    out[2] = fma(p[2][2], w2, fma(p[2][1], w1, p[2][0] * w0));
 }
 
 // golemflavor/llh.py:32-54 multi_gaussian = log(mvn.pdf) + offset.  scipy evaluates
@@ -234,11 +256,12 @@ __device__ __forceinline__ double log_of_exp(double x, bool live = true)
 
 __device__ __forceinline__ double gauss_llh(const GfCommon& c, const double fr[3], bool live = true)
 {
-    const double d0 = (fr[0] - c.bf[0]) * c.inv_smear;
-    const double d1 = (fr[1] - c.bf[1]) * c.inv_smear;
-    const double d2 = (fr[2] - c.bf[2]) * c.inv_smear;
-    const double maha = fma(d2, d2, fma(d1, d1, d0 * d0));
-    const double logpdf = -0.5 * (c.gauss_c0 + maha);
+    // maha = sum ((fr - bf) / smearing)^2;  logpdf = -0.5 (c0 + maha) = fma(-0.5/smearing^2, |fr-bf|^2, -0.5 c0)
+    const double d0 = fr[0] - c.bf[0];
+    const double d1 = fr[1] - c.bf[1];
+    const double d2 = fr[2] - c.bf[2];
+    const double r2 = fma(d2, d2, fma(d1, d1, d0 * d0));
+    const double logpdf = fma(c.gauss_mh, r2, c.gauss_k);
     return log_of_exp(logpdf, live) + c.offset;
 }
 
