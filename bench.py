@@ -196,7 +196,7 @@ def main():
                        "evals_per_step_per_gpu": n, "ndim": 6, "parallelism": "independent ensembles sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
-                         "kernel": "k_lnprob_sm<6, SM_GAUSS>"},
+                         "kernel": "k_lnprob_sm_fast<6, SM_GAUSS, canonical, no fr>"},
         }
         if gathered_ok is not None:
             out["rccl_gather_ok"] = gathered_ok
