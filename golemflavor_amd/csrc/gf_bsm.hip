@@ -60,15 +60,17 @@ __device__ __forceinline__ Herm3 rank2(double w1, const double ar[3], const doub
 }
 
 // Columns 1 and 2 of the mixing matrix for (s12^2, c13^4, s23^2, delta): fr.py:116-162, SURVEY A.2.
-__device__ __forceinline__ void mixing_cols12(double s12_2, double c13_4, double s23_2, double dcp,
+// Once (twice for texture NONE) per walker against 20 bin diagonalisations: kept out of line so that its
+// literals and temporaries do not inflate the bin loop's register allocation.
+__device__ __attribute__((noinline)) void mixing_cols12(double s12_2, double c13_4, double s23_2, double dcp,
                                               double c1r[3], double c1i[3], double c2r[3], double c2i[3])
 {
-    const double c13_2 = sqrt(c13_4);
-    const double s12 = sqrt(s12_2), c12 = sqrt(1.0 - s12_2);
-    const double c13 = sqrt(c13_2), s13 = sqrt(1.0 - c13_2);
-    const double s23 = sqrt(s23_2), c23 = sqrt(1.0 - s23_2);
+    const double c13_2 = fast_sqrt(c13_4);
+    const double s12 = fast_sqrt(s12_2), c12 = fast_sqrt(1.0 - s12_2);
+    const double c13 = fast_sqrt(c13_2), s13 = fast_sqrt(1.0 - c13_2);
+    const double s23 = fast_sqrt(s23_2), c23 = fast_sqrt(1.0 - s23_2);
     double sd, cd;
-    sincos(dcp, &sd, &cd);
+    fast_sincos(dcp, &sd, &cd);
     // column 1: (s12 c13, c12 c23 - s12 s23 s13 e^{id}, -c12 s23 - s12 c23 s13 e^{id})
     const double t1 = s12 * s23 * s13, t2 = s12 * c23 * s13;
     c1r[0] = s12 * c13;            c1i[0] = 0.0;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void mixing_cols12(double s12_2, double c13_4, double
 template <bool CHECK_UNI>
 __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], double& residual)
 {
-    const double s = 1.0 / ((h_in.d0 + h_in.d1) + h_in.d2);
+    const double s = fast_rcp((h_in.d0 + h_in.d1) + h_in.d2);
     const double d0 = h_in.d0 * s, d1 = h_in.d1 * s, d2 = h_in.d2 * s;
     const double r01 = h_in.r01 * s, i01 = h_in.i01 * s;
     const double r02 = h_in.r02 * s, i02 = h_in.i02 * s;
@@ -102,12 +104,12 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
     const double det = fma(d0 * d1, d2, 2.0 * re3) - fma(d0, o12, fma(d1, o02, d2 * o01));
     const double Q = fma(-3.0, b, 1.0) * (1.0 / 9.0);                 // (a^2 - 3b)/9, a = -1
     const double R = (fma(9.0, b, -2.0) - 27.0 * det) * (1.0 / 54.0); // (2a^3 - 9ab + 27c)/54
-    const double sq = sqrt(Q);
-    double x = R / (Q * sq);
+    const double sq = fast_sqrt(Q);
+    double x = R * fast_rcp(Q * sq);
     x = fmin(1.0, fmax(-1.0, x));
-    const double phi = acos(x) * (1.0 / 3.0);
+    const double phi = fast_acos(x) * (1.0 / 3.0);
     double sp, cp;
-    sincos(phi, &sp, &cp);
+    sincos_small(phi, &sp, &cp);
     const double m2 = -2.0 * sq;
     const double HS3 = 0.8660254037844386;                            // sqrt(3)/2
     double E[3];
@@ -121,7 +123,7 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = (i + 1) % 3, k = (i + 2) % 3;
-        const double inv = 1.0 / ((E[i] - E[j]) * (E[i] - E[k]));
+        const double inv = fast_rcp((E[i] - E[j]) * (E[i] - E[k]));
 #pragma unroll
         for (int a = 0; a < 3; ++a) p[a][i] = fma(dd[a] - E[j], dd[a] - E[k], os[a]) * inv;
     }
@@ -143,7 +145,7 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
             const double Ci = fma(-i01, e2, -fma(i12, r02, -r12 * i02));
             const double a2 = fma(Ar, Ar, Ai * Ai), b2 = fma(Br, Br, Bi * Bi), c2 = fma(Cr, Cr, Ci * Ci);
             const double S = fma(a2, b2, fma(a2, c2, b2 * c2));
-            const double invS = 1.0 / S;
+            const double invS = fast_rcp(S);
             trf += (fma(b2, c2, fma(a2, c2, a2 * b2))) * invS;          // = 1 up to rounding (and NaN)
             // conj(A) conj(B) = (Ar Br - Ai Bi) - i (Ar Bi + Ai Br)
             const double abr = fma(Ar, Br, -Ai * Bi), abi = -fma(Ar, Bi, Ai * Br);
@@ -156,8 +158,8 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
             // (XX^+)_12 += |A|^2 C conj(B) / S
             f12r = fma(a2 * bcr, invS, f12r); f12i = fma(a2 * bci, invS, f12i);
         }
-        const double off = sqrt(fma(f01r, f01r, f01i * f01i)) + sqrt(fma(f02r, f02r, f02i * f02i)) +
-                           sqrt(fma(f12r, f12r, f12i * f12i));
+        const double off = fast_sqrt(fma(f01r, f01r, f01i * f01i)) + fast_sqrt(fma(f02r, f02r, f02i * f02i)) +
+                           fast_sqrt(fma(f12r, f12r, f12i * f12i));
         const double rt = fabs(trf - 3.0);
         const double rs = fabs(fma(2.0, off, trf) - 3.0);
         double r = fmax(rt, rs);
@@ -169,8 +171,8 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
 // flux_averaged_BSMu for one walker (fr.py:403-458).  Returns the normalised composition and the worst
 // unitarity residual over the bins.
 template <bool CHECK_UNI>
-__device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* row,
-                                             double fr[3], double& residual)
+__device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
+                                             const double* row, double fr[3], double& residual)
 {
     // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
     double c1r[3], c1i[3], c2r[3], c2i[3];
@@ -179,7 +181,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     const Herm3 S = rank2(pick(row, c.idx_mass[0], c.mass_fixed[0]), c1r, c1i,
                           pick(row, c.idx_mass[1], c.mass_fixed[1]), c2r, c2i);
     // NP part, per walker: sc1 T1 + sc2 T2, sc2 = 10^logLam, sc1 = sc2/100   (fr.py:380-393)
-    const double sc2 = pow(10.0, pick(row, c.idx_scale, c.scale_fixed));
+    const double sc2 = pow10_cold(pick(row, c.idx_scale, c.scale_fixed));
     const double sc1 = sc2 / 100.0;
     Herm3 N;
     if (tb->texture == TEX_NONE) {
@@ -187,12 +189,13 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
                       pick(row, c.idx_mm[2], c.mm_fixed[2]), pick(row, c.idx_mm[3], c.mm_fixed[3]), c1r, c1i, c2r, c2i);
         N = rank2(sc1, c1r, c1i, sc2, c2r, c2i);
     } else {
-        N.d0 = fma(sc1, tb->t1_re[0], sc2 * tb->t2_re[0]);
-        N.d1 = fma(sc1, tb->t1_re[4], sc2 * tb->t2_re[4]);
-        N.d2 = fma(sc1, tb->t1_re[8], sc2 * tb->t2_re[8]);
-        N.r01 = fma(sc1, tb->t1_re[1], sc2 * tb->t2_re[1]); N.i01 = fma(sc1, tb->t1_im[1], sc2 * tb->t2_im[1]);
-        N.r02 = fma(sc1, tb->t1_re[2], sc2 * tb->t2_re[2]); N.i02 = fma(sc1, tb->t1_im[2], sc2 * tb->t2_im[2]);
-        N.r12 = fma(sc1, tb->t1_re[5], sc2 * tb->t2_re[5]); N.i12 = fma(sc1, tb->t1_im[5], sc2 * tb->t2_im[5]);
+        // ttab (LDS): the 18 entries of T1, T2 that a Hermitian 3x3 needs, laid out {t1, t2} pairs
+        N.d0 = fma(sc1, ttab[0], sc2 * ttab[1]);
+        N.d1 = fma(sc1, ttab[2], sc2 * ttab[3]);
+        N.d2 = fma(sc1, ttab[4], sc2 * ttab[5]);
+        N.r01 = fma(sc1, ttab[6], sc2 * ttab[7]);   N.i01 = fma(sc1, ttab[8], sc2 * ttab[9]);
+        N.r02 = fma(sc1, ttab[10], sc2 * ttab[11]); N.i02 = fma(sc1, ttab[12], sc2 * ttab[13]);
+        N.r12 = fma(sc1, ttab[14], sc2 * ttab[15]); N.i12 = fma(sc1, ttab[16], sc2 * ttab[17]);
     }
     const double src[3] = {c.src_fixed[0], c.src_fixed[1], c.src_fixed[2]};
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
@@ -211,17 +214,53 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         propagate(p, src, c.src_fixed_sum, f);                      // fr.py:451
         a0 = fma(f[0], w, a0); a1 = fma(f[1], w, a1); a2 = fma(f[2], w, a2);   // fr.py:454
     }
-    const double inv = 1.0 / ((a0 + a1) + a2);                      // fr.py:457
+    const double inv = fast_rcp((a0 + a1) + a2);                    // fr.py:457
     fr[0] = a0 * inv; fr[1] = a1 * inv; fr[2] = a2 * inv;
 }
 
+// box + priors from the LDS constant table (same layout as the SM kernels: {lo, hi, loc, 1/sigma} per
+// column), branch-free
+template <int NDIM>
+__device__ __forceinline__ bool lnprior_tab(const double* ctab, const double* row, int ndim_rt, double prior_const,
+                                            double& lp)
+{
+    const int ndim = NDIM ? NDIM : ndim_rt;
+    bool inbox = true;
+    double acc = 0.0;
+#pragma unroll
+    for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double x = row[d];
+        const double2 lh = *reinterpret_cast<const double2*>(ctab + 4 * d);
+        const double2 ls = *reinterpret_cast<const double2*>(ctab + 4 * d + 2);
+        inbox = inbox & (x >= lh.x) & (x <= lh.y);
+        const double z = (x - ls.x) * ls.y;
+        acc = fma(-0.5 * z, z, acc);
+    }
+    lp = acc + prior_const;
+    return inbox;
+}
+
 template <int NDIM, bool WITH_LLH, bool CHECK_UNI>
-__global__ __launch_bounds__(GF_BLOCK) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
-                                                   const double* __restrict__ theta, int layout, int64_t n,
-                                                   double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                   int32_t* __restrict__ status)
+__global__ __launch_bounds__(GF_BLOCK, 2) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
+                                                      const double* __restrict__ ptab,
+                                                      const double* __restrict__ theta, int layout, int64_t n,
+                                                      double* __restrict__ lnprob, double* __restrict__ fr_out,
+                                                      int32_t* __restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
+    double* ttab = ctab + GF_MAX_DIM * 4;       // texture projector entries, see flux_average
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 18) {
+        // {t1, t2} pairs: re[0], re[4], re[8], re[1], im[1], re[2], im[2], re[5], im[5]
+        const int k = threadIdx.x - 64, e = k >> 1;
+        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
+        const bool im = e == 4 || e == 6 || e == 8;
+        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
+        ttab[k] = srcp[idx];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int wave = threadIdx.x / GF_WAVE;
     const int ndim = NDIM ? NDIM : c.ndim;
@@ -236,13 +275,13 @@ __global__ __launch_bounds__(GF_BLOCK) void k_bsm(const GfCommon c, const GfBsm*
             const double* row = tile + lane * ndim;
             double lp = 0.0;
             bool inbox = true;
-            if (WITH_LLH) inbox = lnprior<NDIM>(c, row, lp);
+            if (WITH_LLH) inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
             double fr[3] = {gf_nan(), gf_nan(), gf_nan()};
             double val = -gf_inf();
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
                 double residual = 0.0;
-                flux_average<CHECK_UNI>(c, tb, row, fr, residual);
+                flux_average<CHECK_UNI>(c, tb, ttab, row, fr, residual);
                 st = ST_OK;
                 if (CHECK_UNI && !(residual < UNI_THRESHOLD)) st = ST_NON_UNITARY;
                 if (WITH_LLH) {
@@ -274,12 +313,12 @@ inline int grid_for(int64_t work_items, int per_block, int cus)
 }
 
 template <int NDIM>
-hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int with_llh,
-                    double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, const double* ptab, const double* theta, int layout, int64_t n,
+                    int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     const int grid = grid_for(n, GF_BLOCK, cus);
     const bool chk = status != nullptr;
-#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU>), dim3(grid), dim3(GF_BLOCK), 0, s, c, d_bsm, theta, layout, n, lnprob, fr, status)
+#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU>), dim3(grid), dim3(GF_BLOCK), 0, s, c, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
     if (with_llh) { if (chk) GF_GO(true, true); else GF_GO(true, false); }
     else          { if (chk) GF_GO(false, true); else GF_GO(false, false); }
 #undef GF_GO
@@ -288,13 +327,12 @@ hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, const double* theta, 
 
 }  // namespace
 
-hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, const GfBsm& h_bsm, const double* theta, int layout,
+hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
-    (void)h_bsm;
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_bsm, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 12: return launch_n<12>(c, d_bsm, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_n<0>(c, d_bsm, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 7: return launch_n<7>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 12: return launch_n<12>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    default: return launch_n<0>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
     }
 }

@@ -114,7 +114,7 @@ int launch_lnprob(gf_model* m, const double* d_theta, int layout, int64_t n, dou
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->hb, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, m->stream);
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, m->stream);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
@@ -126,7 +126,7 @@ int launch_propagate(gf_model* m, const double* d_theta, int layout, int64_t n, 
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->hb, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, m->stream);
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, m->stream);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");

@@ -49,6 +49,9 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
+// library sin/cos for huge or non-finite arguments, out of line (Payne-Hanek needs ~100 registers)
+__device__ __attribute__((noinline)) void sincos_cold(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+
 // sin and cos of x, |x| < 2^20 * pi/2: three-step Cody-Waite reduction with FMA (33-bit pieces of pi/2,
 // the published fdlibm split), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error
 // <= ~2e-16.  Larger |x| (never a physical phase) take the library path.
@@ -109,6 +112,55 @@ __device__ __forceinline__ double fast_cos_phase(double x)
     q = fma(z, q, -0.16666666666666657);
     return fma(u * z, q, u);
 }
+
+// sin and cos of phi in [0, 1.1] (the cubic solver's angle acos(x)/3 <= pi/3): no argument reduction;
+// odd / even minimax polynomials fitted in 50-digit arithmetic (abs error <= 2.3e-16 each).
+__device__ __forceinline__ void sincos_small(double u, double* sn, double* cs)
+{
+    const double z = u * u;
+    double q = fma(z, 2.7117413873509064e-15, -7.641995277350052e-13);
+    q = fma(z, q, 1.605889634387573e-10);
+    q = fma(z, q, -2.505210587009456e-08);
+    q = fma(z, q, 2.75573191979119e-06);
+    q = fma(z, q, -0.00019841269841110079);
+    q = fma(z, q, 0.008333333333332799);
+    q = fma(z, q, -0.16666666666666657);
+    *sn = fma(u * z, q, u);
+    double c = fma(z, 4.695137892341541e-14, -1.1468837412893726e-11);
+    c = fma(z, c, 2.0876733673699156e-09);
+    c = fma(z, c, -2.755731905787651e-07);
+    c = fma(z, c, 2.4801587300891894e-05);
+    c = fma(z, c, -0.0013888888888887252);
+    c = fma(z, c, 0.04166666666666665);
+    c = fma(z, c, -0.5);
+    *cs = fma(z, c, 1.0);
+}
+
+// acos(x), x in [-1, 1]: the fdlibm scheme (asin(s) = s + s R(s^2), R = z p(z)/q(z); |x| > 1/2 goes through
+// s = sqrt((1-|x|)/2)) written branch-free.  Abs error a few 1e-16 rad.
+__device__ __forceinline__ double fast_acos(double x)
+{
+    const double ax = fabs(x);
+    const bool big = ax > 0.5;
+    const double z = big ? fma(-0.5, ax, 0.5) : x * x;
+    const double s = big ? fast_sqrt(z) : ax;
+    double p = fma(z, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    p = fma(z, p, -4.00555345006794114027e-02);
+    p = fma(z, p, 2.01212532134862925881e-01);
+    p = fma(z, p, -3.25565818622400915405e-01);
+    p = fma(z, p, 1.66666666666666657415e-01);
+    double q = fma(z, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    q = fma(z, q, 2.02094576023350569471e+00);
+    q = fma(z, q, -2.40339491173441421878e+00);
+    q = fma(z, q, 1.0);
+    const double r = (z * p) * fast_rcp(q);
+    const double as = fma(s, r, s);                                  // asin(s)
+    const double a = big ? as + as : 1.5707963267948966 - as;        // acos(|x|)
+    return x < 0.0 ? 3.141592653589793 - a : a;
+}
+
+// 10^x for the NP scale (fr.py:380 np.power(10., logLam)); once per walker, out of line.
+__device__ __attribute__((noinline)) double pow10_cold(double x) { return pow(10.0, x); }
 
 // ---------------------------------------------------------------------------------------------
 // Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).
