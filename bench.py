@@ -96,15 +96,28 @@ def cpu_baseline(ps, bf, theta, sample):
             "single_thread_value": rate1}, ref
 
 
+def _claim_stdout():
+    """Keep fd 1 clean for the ONE JSON line: gloo and RCCL print banners to the C-level stdout, so
+    everything else in this process is pointed at stderr; returns the stream the JSON line goes to."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     a = parse()
+    json_out = _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "GF_BENCH_DEVICE" in os.environ:      # rehearsal on a 1-GPU box: every rank on the same device
+        local_rank = int(os.environ["GF_BENCH_DEVICE"])
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     dist = None
     comm = None
+    rccl_error = None
     L = _lib.lib()
     ps, bf, desc = notebook_descriptor()
     if world > 1:
@@ -112,20 +125,38 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        # RCCL communicator of the library itself: unique id travels over the gloo store
-        ids = [None]
-        if rank == 0:
-            buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
-            _lib.check(L.gf_comm_unique_id(buf), "gf_comm_unique_id")
-            ids = [bytes(buf)]
-        dist.broadcast_object_list(ids, src=0)
-        idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(ids[0])
-        h = C.c_void_p()
-        _lib.check(L.gf_comm_create(idb, rank, world, local_rank, C.byref(h)), "gf_comm_create")
-        comm = h
-        # fixed physics constants: rank 0's packed descriptor is the one everybody uses
-        raw = (C.c_uint8 * C.sizeof(desc)).from_buffer(desc)
-        _lib.check(L.gf_comm_broadcast(comm, raw, C.sizeof(desc), 0), "gf_comm_broadcast")
+        # RCCL communicator of the library itself: unique id travels over the gloo store.  The timed
+        # region has no collective, so an RCCL problem must not cost the measurement: fall back to gloo
+        # for the descriptor broadcast and report the failure in the JSON line.
+        rccl_error = None
+        try:
+            ids = [None]
+            if rank == 0:
+                buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
+                _lib.check(L.gf_comm_unique_id(buf), "gf_comm_unique_id")
+                ids = [bytes(buf)]
+            dist.broadcast_object_list(ids, src=0)
+            idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(ids[0])
+            h = C.c_void_p()
+            _lib.check(L.gf_comm_create(idb, rank, world, local_rank, C.byref(h)), "gf_comm_create")
+            comm = h
+            # fixed physics constants: rank 0's packed descriptor is the one everybody uses
+            raw = (C.c_uint8 * C.sizeof(desc)).from_buffer(desc)
+            _lib.check(L.gf_comm_broadcast(comm, raw, C.sizeof(desc), 0), "gf_comm_broadcast")
+        except Exception as exc:           # noqa: BLE001
+            rccl_error = "%s: %s" % (type(exc).__name__, exc)
+            comm = None
+        flags = [rccl_error]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rccl_error)
+        if any(g is not None for g in gathered):
+            rccl_error = next(g for g in gathered if g is not None)
+            if comm is not None:
+                L.gf_comm_destroy(comm)
+                comm = None
+            blob = [bytes(memoryview(desc))] if rank == 0 else [None]
+            dist.broadcast_object_list(blob, src=0)
+            desc = _lib.GfModelDesc.from_buffer_copy(blob[0])
 
     n = a.walkers * a.ensembles
     model = Model(desc, device=local_rank)
@@ -164,12 +195,16 @@ def main():
     # after the timed region: gather one chain block (the first ensemble's lnprob) from every rank
     gathered_ok = None
     if comm is not None:
-        blk = 8 * a.walkers
-        d_all = model.alloc(blk * world)
-        _lib.check(L.gf_comm_allgather(comm, d_out.ptr, d_all.ptr, blk), "gf_comm_allgather")
-        allv = d_all.download((world, a.walkers))
-        mine = d_out.download((a.walkers,))
-        gathered_ok = bool(np.array_equal(allv[rank], mine, equal_nan=True))
+        try:
+            blk = 8 * a.walkers
+            d_all = model.alloc(blk * world)
+            _lib.check(L.gf_comm_allgather(comm, d_out.ptr, d_all.ptr, blk), "gf_comm_allgather")
+            allv = d_all.download((world, a.walkers))
+            mine = d_out.download((a.walkers,))
+            gathered_ok = bool(np.array_equal(allv[rank], mine, equal_nan=True))
+        except Exception as exc:           # noqa: BLE001
+            rccl_error = "%s: %s" % (type(exc).__name__, exc)
+            gathered_ok = False
 
     if rank == 0:
         evals = float(n) * a.steps * world
@@ -200,6 +235,8 @@ def main():
         }
         if gathered_ok is not None:
             out["rccl_gather_ok"] = gathered_ok
+        if rccl_error is not None:
+            out["rccl_error"] = rccl_error
         if world == 1 and not a.no_cpu_baseline:
             cb, ref = cpu_baseline(ps, bf, theta, a.cpu_sample)
             got = d_out.download((len(ref),))
@@ -207,7 +244,8 @@ def main():
                 out["parity_max_rel_vs_oracle"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
     if comm is not None:
         L.gf_comm_destroy(comm)
