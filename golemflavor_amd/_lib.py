@@ -79,6 +79,16 @@ SIGNATURES = {
     "gf_event_destroy": (C.c_int, [_vp]),
     "gf_event_record": (C.c_int, [_vp, _vp]),
     "gf_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "gf_sampler_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.POINTER(_vp)]),
+    "gf_sampler_destroy": (None, [_vp]),
+    "gf_sampler_set_state": (C.c_int, [_vp, _dp]),
+    "gf_sampler_run": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int]),
+    "gf_sampler_sync": (C.c_int, [_vp]),
+    "gf_sampler_reset": (C.c_int, [_vp]),
+    "gf_sampler_nstored": (C.c_int64, [_vp]),
+    "gf_sampler_iterations": (C.c_int64, [_vp]),
+    "gf_sampler_get_state": (C.c_int, [_vp, _dp, _dp]),
+    "gf_sampler_get_chain": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gf_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "gf_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gf_comm_destroy": (None, [_vp]),

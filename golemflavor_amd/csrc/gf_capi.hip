@@ -340,6 +340,14 @@ void gf_model_destroy(gf_model* m)
 
 int gf_model_ndim(const gf_model* m) { return m ? m->c.ndim : -1; }
 
+// internal (not in the public header): lets gf_sampler.hip reach the model's constants and stream
+int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, void** stream, int* device)
+{
+    if (!m) return GF_ERR_INVALID_ARG;
+    *c = &m->c; *d_bsm = m->d_bsm; *d_ptab = m->d_ptab; *stream = (void*)m->stream; *device = m->device;
+    return GF_OK;
+}
+
 // ---- host-buffer entry points ------------------------------------------------------------
 static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status,
                     bool with_llh)

@@ -50,7 +50,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 }
 
 // library sin/cos for huge or non-finite arguments, out of line (Payne-Hanek needs ~100 registers)
-__device__ __attribute__((noinline)) void sincos_cold(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+static __device__ __attribute__((noinline)) void sincos_cold(double x, double* sn, double* cs) { sincos(x, sn, cs); }
 
 // sin and cos of x, |x| < 2^20 * pi/2: three-step Cody-Waite reduction with FMA (33-bit pieces of pi/2,
 // the published fdlibm split), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error
@@ -91,7 +91,7 @@ __device__ __forceinline__ double fast_cos(double x)
 }
 
 // Cold, out-of-line general cosine (keeps its literals out of the hot loop's register budget).
-__device__ __attribute__((noinline)) double cos_general(double x) { return fast_cos(x); }
+static __device__ __attribute__((noinline)) double cos_general(double x) { return fast_cos(x); }
 
 // cos(x) for a CP phase.  Every paramset of the reference boxes dcp into [0, 2 pi]
 // (scripts/fr.py:41, examples/inference.ipynb:253), so the fast path folds that interval onto
@@ -160,7 +160,7 @@ __device__ __forceinline__ double fast_acos(double x)
 }
 
 // 10^x for the NP scale (fr.py:380 np.power(10., logLam)); once per walker, out of line.
-__device__ __attribute__((noinline)) double pow10_cold(double x) { return pow(10.0, x); }
+static __device__ __attribute__((noinline)) double pow10_cold(double x) { return pow(10.0, x); }
 
 // ---------------------------------------------------------------------------------------------
 // Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).
@@ -288,7 +288,7 @@ __device__ __forceinline__ void propagate(const double p[3][3], const double src
 // or -inf.  Emulated: y = exp(logpdf) / 2^-1074 rounded to an integer count of subnormal ulps.
 // Cold path, deliberately not inlined: exp()/log() bring ~25 fp64 literals whose materialisation the
 // compiler would otherwise hoist out of the tile loop and keep live in (scarce) scalar registers.
-__device__ __attribute__((noinline)) double log_of_exp_band(double x)
+static __device__ __attribute__((noinline)) double log_of_exp_band(double x)
 {
     const double HI = 744.4400719213812, LO = 4.422444340918698e-14;   // 1074 ln 2 = HI + LO
     const double t = x + HI;                            // exact (both multiples of 2^-43, |t| < 64)
@@ -337,6 +337,62 @@ __device__ __forceinline__ void sm_composition(const GfCommon& c, const double* 
         src_sum = c.src_fixed_sum;
     }
     propagate(p, src, src_sum, fr);
+}
+
+
+// one walker: box + priors from the LDS constant table, then the mode's likelihood.  Branch-free: the
+// likelihood of an out-of-box walker is computed and discarded (a wave runs it anyway if any lane is
+// inside), which keeps the LDS reads and the fp64 chain in one straight-line block.
+// SAMPLED = 1: every mixing parameter and both source angles are columns of theta (drops the fixed-value
+// selects and their scalar constants); 2: additionally in the canonical order s12, c13, s23, dcp, src1,
+// src2 = columns 0..5 (the notebook posterior), so no named re-reads from LDS; 0: general.
+template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
+__device__ __forceinline__ void eval_walker(const GfCommon& c, const double* ctab, const double* row, int ndim_rt,
+                                            double& val, double fr[3], int& st)
+{
+    const int ndim = NDIM ? NDIM : ndim_rt;
+    bool inbox = true;
+    double acc = 0.0;
+#pragma unroll
+    for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double x = row[d];
+        const double2 lh = *reinterpret_cast<const double2*>(ctab + 4 * d);       // lo, hi
+        const double2 ls = *reinterpret_cast<const double2*>(ctab + 4 * d + 2);   // loc, 1/sigma
+        inbox = inbox & (x >= lh.x) & (x <= lh.y);                                 // llh.py:74-78 (NaN fails)
+        const double z = (x - ls.x) * ls.y;
+        acc = fma(-0.5 * z, z, acc);                                               // llh.py:81-90
+#ifdef GF_DIM_BARRIER
+        if ((d % GF_DIM_BARRIER) == GF_DIM_BARRIER - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    const double lp = acc + c.prior_const;
+    double v;
+    if (MODE == MODE_PRIOR_ONLY) {
+        v = lp + c.flat_llh;                             // mc_unitary.py:131,139
+        if (WANT_FR) fr[0] = fr[1] = fr[2] = gf_nan();
+    } else {
+        double f[3];
+        if (SAMPLED == 2) {                              // canonical columns 0..5: reuse the row registers
+            double p[3][3], src[3];
+            pmns_abs2(row[0], row[1], row[2], row[3], p);
+            angles_to_fr(row[4], row[5], src);
+            propagate(p, src, (src[0] + src[1]) + src[2], f);
+        } else if (SAMPLED == 1) {
+            double p[3][3], src[3];
+            pmns_abs2(row[c.idx_sm[0]], row[c.idx_sm[1]], row[c.idx_sm[2]], row[c.idx_sm[3]], p);
+            angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
+            propagate(p, src, (src[0] + src[1]) + src[2], f);
+        } else {
+            sm_composition(c, row, f);
+        }
+        v = lp + gauss_llh(c, f, inbox);                 // ipynb:364
+        if (WANT_FR) {
+            fr[0] = inbox ? f[0] : gf_nan(); fr[1] = inbox ? f[1] : gf_nan(); fr[2] = inbox ? f[2] : gf_nan();
+        }
+    }
+    val = inbox ? v : -gf_inf();                         // llh.py:78 / ipynb:360-361
+    st = inbox ? ((v != v) ? ST_NAN : ST_OK) : ST_OUT_OF_PRIOR;
 }
 
 

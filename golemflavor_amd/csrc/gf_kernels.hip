@@ -32,61 +32,6 @@ using namespace gfdev;
 // AoS tiles are software-pipelined: the 16-B loads of the wave's next tile are issued before the
 // current tile is evaluated, so a wave's HBM latency hides under its own fp64 work.
 
-// one walker: box + priors from the LDS constant table, then the mode's likelihood.  Branch-free: the
-// likelihood of an out-of-box walker is computed and discarded (a wave runs it anyway if any lane is
-// inside), which keeps the LDS reads and the fp64 chain in one straight-line block.
-// SAMPLED = 1: every mixing parameter and both source angles are columns of theta (drops the fixed-value
-// selects and their scalar constants); 2: additionally in the canonical order s12, c13, s23, dcp, src1,
-// src2 = columns 0..5 (the notebook posterior), so no named re-reads from LDS; 0: general.
-template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
-__device__ __forceinline__ void eval_walker(const GfCommon& c, const double* ctab, const double* row, int ndim_rt,
-                                            double& val, double fr[3], int& st)
-{
-    const int ndim = NDIM ? NDIM : ndim_rt;
-    bool inbox = true;
-    double acc = 0.0;
-#pragma unroll
-    for (int d = 0; d < (NDIM ? NDIM : GF_MAX_DIM); ++d) {
-        if (!NDIM && d >= ndim) break;
-        const double x = row[d];
-        const double2 lh = *reinterpret_cast<const double2*>(ctab + 4 * d);       // lo, hi
-        const double2 ls = *reinterpret_cast<const double2*>(ctab + 4 * d + 2);   // loc, 1/sigma
-        inbox = inbox & (x >= lh.x) & (x <= lh.y);                                 // llh.py:74-78 (NaN fails)
-        const double z = (x - ls.x) * ls.y;
-        acc = fma(-0.5 * z, z, acc);                                               // llh.py:81-90
-#ifdef GF_DIM_BARRIER
-        if ((d % GF_DIM_BARRIER) == GF_DIM_BARRIER - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    const double lp = acc + c.prior_const;
-    double v;
-    if (MODE == MODE_PRIOR_ONLY) {
-        v = lp + c.flat_llh;                             // mc_unitary.py:131,139
-        if (WANT_FR) fr[0] = fr[1] = fr[2] = gf_nan();
-    } else {
-        double f[3];
-        if (SAMPLED == 2) {                              // canonical columns 0..5: reuse the row registers
-            double p[3][3], src[3];
-            pmns_abs2(row[0], row[1], row[2], row[3], p);
-            angles_to_fr(row[4], row[5], src);
-            propagate(p, src, (src[0] + src[1]) + src[2], f);
-        } else if (SAMPLED == 1) {
-            double p[3][3], src[3];
-            pmns_abs2(row[c.idx_sm[0]], row[c.idx_sm[1]], row[c.idx_sm[2]], row[c.idx_sm[3]], p);
-            angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
-            propagate(p, src, (src[0] + src[1]) + src[2], f);
-        } else {
-            sm_composition(c, row, f);
-        }
-        v = lp + gauss_llh(c, f, inbox);                 // ipynb:364
-        if (WANT_FR) {
-            fr[0] = inbox ? f[0] : gf_nan(); fr[1] = inbox ? f[1] : gf_nan(); fr[2] = inbox ? f[2] : gf_nan();
-        }
-    }
-    val = inbox ? v : -gf_inf();                         // llh.py:78 / ipynb:360-361
-    st = inbox ? ((v != v) ? ST_NAN : ST_OK) : ST_OUT_OF_PRIOR;
-}
-
 // Hot kernel: AoS theta, compile-time row length, FULL 64-walker tiles only (the launcher hands the
 // ragged remainder to k_lnprob_sm_gen).  Keeping the generic staging out of this loop keeps its
 // induction variables and bounds checks out of the register budget.

@@ -1,0 +1,403 @@
+// gf_sampler.hip -- device-resident affine-invariant ensemble sampler (the emcee step either side of
+// the lnprob path).
+//
+// The reference drives the path through emcee's stretch move (un-vendored, requirements.txt:5; call
+// sites golemflavor/mcmc.py:29-49).  Host-driven, every half-ensemble update costs a PCIe round trip and
+// a launch for a few thousand evaluations.  Here the whole chain stays in HBM: one launch per
+// half-ensemble update does proposal + lnprob + accept in place, for `nchains` independent ensembles
+// stacked in one grid; the host only sees chains at the end.
+//
+// Stretch move (Goodman & Weare 2010, the published algorithm emcee runs by default), for walker k of
+// the active half S with the complementary half C frozen during the launch:
+//     z = ((a-1) u1 + 1)^2 / a,   j ~ U{0..|C|-1},   q = c_j - z (c_j - s_k),
+//     accept iff (ndim-1) ln z + lnp(q) - lnp(s_k) > ln u3.
+// Random numbers: one Philox4x32-10 block per (walker, half-step): counter = (global walker slot,
+// 2*iteration + half), key = seed.  u1 has 53 bits, j and u3 32 bits each.  The accept test is evaluated
+// as ln(z^(ndim-1) / u3) > lnp(s_k) - lnp(q): one logarithm.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <new>
+
+#include "../../include/golemflavor_hip.h"
+#include "gf_consts.h"
+#include "gf_device.hpp"
+#include "gf_bsm_device.hpp"
+#include "gf_launch.h"
+
+namespace {
+using namespace gfdev;
+
+__device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                             uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)m1;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)m0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct StretchArgs {
+    double* pos;            // [nchains][nwalkers][ndim]
+    double* lnp;            // [nchains][nwalkers]
+    uint32_t* naccept;      // [nchains][nwalkers]
+    uint32_t* flags;        // [0]: walkers whose proposal came back NON_UNITARY (reference would raise)
+    double* chain;          // [nchains][nstore_cap][nwalkers][ndim] or null
+    double* lnp_chain;      // [nchains][nstore_cap][nwalkers] or null
+    int64_t store_index;    // slot to write this step into (ignored when chain == null)
+    int64_t nstore_cap;
+    uint64_t seed;
+    uint64_t iteration;
+    int32_t nchains, nwalkers, half;
+    double a;
+};
+
+// lnprob of the proposal held in LDS row `row`
+template <int NDIM, int MODE>
+__device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm* tb, const double* ctab,
+                                                  const double* ttab, const double* row, int ndim, int& st)
+{
+    double val, fr[3];
+    if (MODE == MODE_BSM_GAUSS) {
+        double lp;
+        const bool inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
+        val = -gf_inf();
+        st = ST_OUT_OF_PRIOR;
+        if (inbox) {
+            double residual = 0.0;
+            flux_average<true>(c, tb, ttab, row, fr, residual);
+            st = (residual < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;
+            val = lp + gauss_llh(c, fr);
+            if (val != val && st == ST_OK) st = ST_NAN;
+        }
+    } else {
+        eval_walker<NDIM, MODE, 0, false>(c, ctab, row, ndim, val, fr, st);
+    }
+    return val;
+}
+
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
+                                                          const double* __restrict__ ptab, const StretchArgs s)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * ND];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
+    double* ttab = ctab + GF_MAX_DIM * 4;
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    if (MODE == MODE_BSM_GAUSS && threadIdx.x >= 64 && threadIdx.x < 64 + 18) {
+        const int k = threadIdx.x - 64, e = k >> 1;
+        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
+        const bool im = e == 4 || e == 6 || e == 8;
+        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
+        ttab[k] = srcp[idx];
+    }
+    __syncthreads();
+
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    const int wave = threadIdx.x / GF_WAVE;
+    double* row = tiles[wave] + lane * ndim;
+    const int nhalf = s.nwalkers / 2;
+    const int64_t total = (int64_t)s.nchains * nhalf;
+    const int64_t g = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
+    if (g >= total) return;
+    const int chain = (int)(g / nhalf);
+    const int k = (int)(g - (int64_t)chain * nhalf);
+    const int w = s.half * nhalf + k;                        // this walker, in the active half
+    const int cbase = (1 - s.half) * nhalf;                  // complementary half
+
+    uint32_t r[4];
+    philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(2 * s.iteration + s.half),
+                 (uint32_t)((2 * s.iteration + s.half) >> 32), (uint32_t)s.seed, (uint32_t)(s.seed >> 32), r);
+    const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+    const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
+    const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+    const double zr = fma(s.a - 1.0, u1, 1.0);
+    const double z = zr * zr / s.a;
+
+    const double* sk = s.pos + ((int64_t)chain * s.nwalkers + w) * ndim;
+    const double* cj = s.pos + ((int64_t)chain * s.nwalkers + cbase + j) * ndim;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double cv = cj[d];
+        row[d] = fma(-z, cv - sk[d], cv);                    // q = c_j - z (c_j - s_k)
+    }
+    int st;
+    const double lnq = proposal_lnprob<NDIM, MODE>(c, tb, ctab, ttab, row, ndim, st);
+    const int64_t wi = (int64_t)chain * s.nwalkers + w;
+    const double lnk = s.lnp[wi];
+    // z^(ndim-1) / u3
+    double zp = 1.0;
+    for (int d = 1; d < ndim; ++d) zp *= z;
+    const double lhs = log(zp / u3);
+    bool accept = lhs > lnk - lnq;                           // false for NaN and for lnq = -inf
+    if (st == ST_NON_UNITARY) {                              // the reference raises inside ln_prob here
+        accept = false;
+        atomicAdd(s.flags, 1u);
+    }
+    if (accept) {
+        double* dst = s.pos + wi * ndim;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (!NDIM && d >= ndim) break;
+            dst[d] = row[d];
+        }
+        s.lnp[wi] = lnq;
+        s.naccept[wi] += 1u;
+    }
+    if (s.chain) {
+        double* dst = s.chain + (((int64_t)chain * s.nstore_cap + s.store_index) * s.nwalkers + w) * ndim;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (!NDIM && d >= ndim) break;
+            dst[d] = accept ? row[d] : sk[d];
+        }
+        if (s.lnp_chain)
+            s.lnp_chain[((int64_t)chain * s.nstore_cap + s.store_index) * s.nwalkers + w] = accept ? lnq : lnk;
+    }
+}
+
+template <int NDIM>
+hipError_t launch_stretch_n(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
+{
+    const int64_t total = (int64_t)a.nchains * (a.nwalkers / 2);
+    const int grid = (int)((total + GF_BLOCK - 1) / GF_BLOCK);
+    switch (c.mode) {
+    case MODE_PRIOR_ONLY: hipLaunchKernelGGL((k_stretch<NDIM, MODE_PRIOR_ONLY>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
+    case MODE_SM_GAUSS: hipLaunchKernelGGL((k_stretch<NDIM, MODE_SM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
+    default: hipLaunchKernelGGL((k_stretch<NDIM, MODE_BSM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_stretch(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
+{
+    switch (c.ndim) {
+    case 4: return launch_stretch_n<4>(c, tb, ptab, a, st);
+    case 6: return launch_stretch_n<6>(c, tb, ptab, a, st);
+    case 7: return launch_stretch_n<7>(c, tb, ptab, a, st);
+    case 12: return launch_stretch_n<12>(c, tb, ptab, a, st);
+    default: return launch_stretch_n<0>(c, tb, ptab, a, st);
+    }
+}
+
+}  // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+struct gf_sampler {
+    gf_model* model = nullptr;
+    int nchains = 0, nwalkers = 0, ndim = 0;
+    uint64_t seed = 0, iteration = 0;
+    double a = 2.0;
+    double* d_pos = nullptr;
+    double* d_lnp = nullptr;
+    uint32_t* d_naccept = nullptr;
+    uint32_t* d_flags = nullptr;
+    double* d_chain = nullptr;
+    double* d_lnp_chain = nullptr;
+    int64_t nstore_cap = 0, nstored = 0;
+    int64_t steps_since_reset = 0;
+};
+
+// accessors implemented in gf_capi.hip (gf_model is private to it)
+extern "C" {
+int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, void** stream,
+                      int* device);
+}
+
+namespace {
+thread_local char g_serr[256] = "";
+int sfail(hipError_t e, const char* what)
+{
+    std::snprintf(g_serr, sizeof(g_serr), "%s: %s", what, hipGetErrorString(e));
+    return GF_ERR_HIP;
+}
+#define GFS_HIP(call)                              \
+    do {                                           \
+        hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) return sfail(e_, #call); \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* gf_sampler_last_error(void) { return g_serr; }
+
+int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out)
+{
+    if (!m || !out || nchains < 1 || nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(m, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    if (nwalkers < 2 * c->ndim) return GF_ERR_INVALID_ARG;        // emcee's own requirement
+    gf_sampler* s = new (std::nothrow) gf_sampler();
+    if (!s) return GF_ERR_ALLOC;
+    s->model = m; s->nchains = nchains; s->nwalkers = nwalkers; s->ndim = c->ndim; s->seed = seed; s->a = a;
+    const size_t nw = (size_t)nchains * nwalkers;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_pos, sizeof(double) * nw * s->ndim);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_lnp, sizeof(double) * nw);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_naccept, sizeof(uint32_t) * nw);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, sizeof(uint32_t) * 4);
+    if (e == hipSuccess) e = hipMemset(s->d_naccept, 0, sizeof(uint32_t) * nw);
+    if (e == hipSuccess) e = hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4);
+    if (e != hipSuccess) { int rc = sfail(e, "gf_sampler_create"); gf_sampler_destroy(s); return rc; }
+    *out = s;
+    return GF_OK;
+}
+
+void gf_sampler_destroy(gf_sampler* s)
+{
+    if (!s) return;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) == GF_OK) {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+    }
+    if (s->d_pos) (void)hipFree(s->d_pos);
+    if (s->d_lnp) (void)hipFree(s->d_lnp);
+    if (s->d_naccept) (void)hipFree(s->d_naccept);
+    if (s->d_flags) (void)hipFree(s->d_flags);
+    if (s->d_chain) (void)hipFree(s->d_chain);
+    if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
+    delete s;
+}
+
+// p0: [nchains][nwalkers][ndim] host; evaluates lnprob of the start positions on the device.
+int gf_sampler_set_state(gf_sampler* s, const double* pos)
+{
+    if (!s || !pos) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device);
+    GFS_HIP(hipSetDevice(device));
+    const size_t nw = (size_t)s->nchains * s->nwalkers;
+    GFS_HIP(hipMemcpyAsync(s->d_pos, pos, sizeof(double) * nw * s->ndim, hipMemcpyHostToDevice, (hipStream_t)stream));
+    int rc = gf_lnprob_batch_device(s->model, s->d_pos, GF_LAYOUT_AOS, (int64_t)nw, s->d_lnp, nullptr, nullptr);
+    if (rc != GF_OK) return rc;
+    GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GF_OK;
+}
+
+int gf_sampler_reset(gf_sampler* s)
+{
+    if (!s) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device);
+    GFS_HIP(hipSetDevice(device));
+    GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    GFS_HIP(hipMemset(s->d_naccept, 0, sizeof(uint32_t) * (size_t)s->nchains * s->nwalkers));
+    GFS_HIP(hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4));
+    s->nstored = 0;
+    s->steps_since_reset = 0;
+    return GF_OK;
+}
+
+// Advance every ensemble by nsteps stretch-move steps (2 launches each), asynchronously on the model's
+// stream.  store != 0 appends every `thin`-th step to the device chain (capacity grows as needed).
+int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
+{
+    if (!s || nsteps < 0 || thin < 1) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device);
+    GFS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nw = (size_t)s->nchains * s->nwalkers;
+    if (store) {
+        const int64_t need = s->nstored + (nsteps + thin - 1) / thin;
+        if (need > s->nstore_cap) {
+            // grow: chains are [chain][slot][walker][dim]; a new capacity changes the chain stride, so repack
+            int64_t cap = s->nstore_cap ? s->nstore_cap : 64;
+            while (cap < need) cap *= 2;
+            double *nc = nullptr, *nl = nullptr;
+            GFS_HIP(hipStreamSynchronize(st));
+            GFS_HIP(hipMalloc((void**)&nc, sizeof(double) * nw * s->ndim * cap));
+            GFS_HIP(hipMalloc((void**)&nl, sizeof(double) * nw * cap));
+            if (s->nstored > 0) {
+                for (int ch = 0; ch < s->nchains; ++ch) {
+                    GFS_HIP(hipMemcpy(nc + (size_t)ch * cap * s->nwalkers * s->ndim,
+                                      s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim,
+                                      sizeof(double) * s->nstored * s->nwalkers * s->ndim, hipMemcpyDeviceToDevice));
+                    GFS_HIP(hipMemcpy(nl + (size_t)ch * cap * s->nwalkers, s->d_lnp_chain + (size_t)ch * s->nstore_cap * s->nwalkers,
+                                      sizeof(double) * s->nstored * s->nwalkers, hipMemcpyDeviceToDevice));
+                }
+            }
+            if (s->d_chain) (void)hipFree(s->d_chain);
+            if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
+            s->d_chain = nc; s->d_lnp_chain = nl; s->nstore_cap = cap;
+        }
+    }
+    StretchArgs a;
+    a.pos = s->d_pos; a.lnp = s->d_lnp; a.naccept = s->d_naccept; a.flags = s->d_flags;
+    a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
+    for (int64_t i = 0; i < nsteps; ++i) {
+        const bool keep = store && (i % thin == 0);
+        a.chain = keep ? s->d_chain : nullptr;
+        a.lnp_chain = keep ? s->d_lnp_chain : nullptr;
+        a.store_index = s->nstored;
+        a.iteration = s->iteration;
+        for (int half = 0; half < 2; ++half) {
+            a.half = half;
+            hipError_t e = launch_stretch(*c, tb, ptab, a, st);
+            if (e != hipSuccess) return sfail(e, "stretch launch");
+        }
+        s->iteration += 1;
+        s->steps_since_reset += 1;
+        if (keep) s->nstored += 1;
+    }
+    return GF_OK;
+}
+
+int gf_sampler_sync(gf_sampler* s)
+{
+    if (!s) return GF_ERR_INVALID_ARG;
+    return gf_model_sync(s->model);
+}
+
+int64_t gf_sampler_nstored(const gf_sampler* s) { return s ? s->nstored : -1; }
+int64_t gf_sampler_iterations(const gf_sampler* s) { return s ? s->steps_since_reset : -1; }
+
+// pos [nchains][nwalkers][ndim], lnprob [nchains][nwalkers] (either may be NULL)
+int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob)
+{
+    if (!s) return GF_ERR_INVALID_ARG;
+    int rc = gf_model_sync(s->model);
+    if (rc != GF_OK) return rc;
+    const size_t nw = (size_t)s->nchains * s->nwalkers;
+    if (pos) GFS_HIP(hipMemcpy(pos, s->d_pos, sizeof(double) * nw * s->ndim, hipMemcpyDeviceToHost));
+    if (lnprob) GFS_HIP(hipMemcpy(lnprob, s->d_lnp, sizeof(double) * nw, hipMemcpyDeviceToHost));
+    return GF_OK;
+}
+
+// chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
+// naccepted [nchains][nwalkers], nonunitary[1]; any may be NULL.
+int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary)
+{
+    if (!s) return GF_ERR_INVALID_ARG;
+    int rc = gf_model_sync(s->model);
+    if (rc != GF_OK) return rc;
+    const size_t per = (size_t)s->nwalkers;
+    for (int ch = 0; ch < s->nchains && s->nstored > 0; ++ch) {
+        if (chain)
+            GFS_HIP(hipMemcpy(chain + (size_t)ch * s->nstored * per * s->ndim, s->d_chain + (size_t)ch * s->nstore_cap * per * s->ndim,
+                              sizeof(double) * s->nstored * per * s->ndim, hipMemcpyDeviceToHost));
+        if (lnprob_chain)
+            GFS_HIP(hipMemcpy(lnprob_chain + (size_t)ch * s->nstored * per, s->d_lnp_chain + (size_t)ch * s->nstore_cap * per,
+                              sizeof(double) * s->nstored * per, hipMemcpyDeviceToHost));
+    }
+    if (naccepted) GFS_HIP(hipMemcpy(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost));
+    if (nonunitary) GFS_HIP(hipMemcpy(nonunitary, s->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GF_OK;
+}
+
+}  // extern "C"

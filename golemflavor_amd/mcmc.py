@@ -181,11 +181,167 @@ class EnsembleSampler:
         return results
 
 
-def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1):
+class DeviceEnsembleSampler:
+    """The same sampler, resident on the GPU (`gf_sampler_*` in include/golemflavor_hip.h).
+
+    Proposal, lnprob and accept/reject of a half-ensemble run in ONE kernel launch and the walkers
+    never leave HBM; `nchains` independent ensembles of one posterior are advanced together.  The
+    attribute surface is emcee-2's (`sample`, `run_mcmc`, `reset`, `chain`, `lnprobability`,
+    `acceptance_fraction`, `acor`); with `nchains > 1` the arrays gain a leading chain axis.
+    Random numbers come from Philox4x32-10 keyed by `seed` (reproducible, independent of launch
+    geometry), not from numpy's global state.
+    """
+
+    def __init__(self, nwalkers, dim, lnpostfn, a=2.0, nchains=1, seed=0, threads=1):
+        import ctypes as C
+        from . import _lib
+        model = getattr(lnpostfn, "model", lnpostfn)
+        if not hasattr(model, "_h"):
+            raise TypeError("DeviceEnsembleSampler needs a golemflavor_amd LnProb / Model")
+        if model.ndim != dim:
+            raise AssertionError("dim %d does not match the model's %d parameters" % (dim, model.ndim))
+        if nwalkers % 2:
+            raise AssertionError("The number of walkers must be even.")
+        if nwalkers < 2 * dim:
+            raise AssertionError("The number of walkers needs to be more than twice the dimension "
+                                 "of your parameter space.")
+        self._C, self._lib, self._L = C, _lib, _lib.lib()
+        self.model, self.lnprobfn = model, lnpostfn
+        self.k, self.dim, self.a, self.nchains = int(nwalkers), int(dim), float(a), int(nchains)
+        h = C.c_void_p()
+        _lib.check(self._L.gf_sampler_create(model._h, self.nchains, self.k, int(seed), self.a, C.byref(h)),
+                   "gf_sampler_create")
+        self._h = h
+        self._have_state = False
+        self.on_nonunitary = getattr(lnpostfn, "on_nonunitary", "raise")
+
+    # -- control ------------------------------------------------------------------------
+    def _set_state(self, p0):
+        p = np.ascontiguousarray(p0, dtype=np.float64)
+        if p.shape == (self.k, self.dim) and self.nchains == 1:
+            p = p[None]
+        if p.shape != (self.nchains, self.k, self.dim):
+            raise ValueError("p0 must have shape (%d, %d, %d), got %s" % (self.nchains, self.k, self.dim, p.shape))
+        if not np.all(np.isfinite(p)):
+            raise ValueError("At least one parameter value was infinite or NaN.")
+        self._lib.check(self._L.gf_sampler_set_state(self._h, p.ctypes.data_as(self._lib._dp)), "gf_sampler_set_state")
+        self._have_state = True
+
+    def reset(self):
+        self._lib.check(self._L.gf_sampler_reset(self._h), "gf_sampler_reset")
+
+    def run_mcmc(self, pos0, N, thin=1, storechain=True):
+        """Advance N steps (asynchronous launches, then one sync); returns (pos, lnprob, None)."""
+        if pos0 is not None:
+            self._set_state(pos0)
+        if not self._have_state:
+            raise ValueError("no starting position")
+        self._lib.check(self._L.gf_sampler_run(self._h, int(N), int(thin), 1 if storechain else 0), "gf_sampler_run")
+        self._lib.check(self._L.gf_sampler_sync(self._h), "gf_sampler_sync")
+        self._check_flags()
+        pos, lnp = self.state
+        return pos, lnp, None
+
+    def sample(self, p0, iterations=1, thin=1, storechain=True, chunk=None):
+        """Generator with emcee-2's shape: yields (pos, lnprob, state) after every `chunk` steps
+        (default: ~100 yields per call) so progress bars keep working without a sync per step."""
+        if p0 is not None:
+            self._set_state(p0)
+        chunk = int(chunk or max(1, iterations // 100))
+        done = 0
+        while done < iterations:
+            m = min(chunk, iterations - done)
+            self._lib.check(self._L.gf_sampler_run(self._h, m, int(thin), 1 if storechain else 0), "gf_sampler_run")
+            self._lib.check(self._L.gf_sampler_sync(self._h), "gf_sampler_sync")
+            self._check_flags()
+            done += m
+            pos, lnp = self.state
+            for _ in range(m):
+                yield pos, lnp, None
+
+    def _check_flags(self):
+        n = (self._C.c_uint32 * 1)()
+        self._lib.check(self._L.gf_sampler_get_chain(self._h, None, None, None, n), "gf_sampler_get_chain")
+        if n[0] and self.on_nonunitary == "raise":
+            # reference: AssertionError out of test_unitarity kills the run (fr.py:493-498)
+            raise AssertionError("Matrix is not unitary! (%d proposals)" % n[0])
+
+    # -- results --------------------------------------------------------------------------
+    @property
+    def iterations(self):
+        return int(self._L.gf_sampler_iterations(self._h))
+
+    @property
+    def state(self):
+        pos = np.empty((self.nchains, self.k, self.dim))
+        lnp = np.empty((self.nchains, self.k))
+        self._lib.check(self._L.gf_sampler_get_state(self._h, pos.ctypes.data_as(self._lib._dp),
+                                                     lnp.ctypes.data_as(self._lib._dp)), "gf_sampler_get_state")
+        return (pos[0], lnp[0]) if self.nchains == 1 else (pos, lnp)
+
+    def _fetch(self):
+        ns = int(self._L.gf_sampler_nstored(self._h))
+        chain = np.empty((self.nchains, ns, self.k, self.dim))
+        lnp = np.empty((self.nchains, ns, self.k))
+        nacc = np.empty((self.nchains, self.k), dtype=np.uint32)
+        self._lib.check(self._L.gf_sampler_get_chain(
+            self._h, chain.ctypes.data_as(self._lib._dp), lnp.ctypes.data_as(self._lib._dp),
+            nacc.ctypes.data_as(self._C.POINTER(self._C.c_uint32)), None), "gf_sampler_get_chain")
+        return chain, lnp, nacc
+
+    @property
+    def chain(self):
+        """(nwalkers, nsteps, ndim) like emcee-2 [(nchains, nwalkers, nsteps, ndim) when nchains > 1]."""
+        c = np.ascontiguousarray(self._fetch()[0].transpose(0, 2, 1, 3))
+        return c[0] if self.nchains == 1 else c
+
+    @property
+    def flatchain(self):
+        c = self.chain
+        return c.reshape(-1, self.dim) if self.nchains == 1 else c.reshape(self.nchains, -1, self.dim)
+
+    @property
+    def lnprobability(self):
+        lp = np.ascontiguousarray(self._fetch()[1].transpose(0, 2, 1))
+        return lp[0] if self.nchains == 1 else lp
+
+    @property
+    def acceptance_fraction(self):
+        nacc = self._fetch()[2].astype(np.float64) / max(self.iterations, 1)
+        return nacc[0] if self.nchains == 1 else nacc
+
+    @property
+    def acor(self):
+        return self.get_autocorr_time()
+
+    def get_autocorr_time(self, c=5, tol=50):
+        ch = self.chain
+        if self.nchains == 1:
+            return integrated_time(np.mean(ch, axis=0), c=c, tol=tol)
+        return np.array([integrated_time(np.mean(x, axis=0), c=c, tol=tol) for x in ch])
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._L.gf_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident=False, seed=0):
     """Run the MCMC: burn-in, reset, production; returns samples reshaped to (-1, ndim).
 
-    Same signature, prints and return as golemflavor/mcmc.py:27-53."""
-    sampler = EnsembleSampler(nwalkers, ndim, ln_prob, threads=threads)
+    Same signature, prints and return as golemflavor/mcmc.py:27-53.  `device_resident=True` (needs a
+    golemflavor_amd LnProb) runs the whole chain on the GPU (DeviceEnsembleSampler) instead of one
+    launch per half-ensemble from the host."""
+    if device_resident:
+        sampler = DeviceEnsembleSampler(nwalkers, ndim, ln_prob, seed=seed)
+    else:
+        sampler = EnsembleSampler(nwalkers, ndim, ln_prob, threads=threads)
 
     print("Running burn-in")
     pos = p0

@@ -162,6 +162,28 @@ int gf_event_destroy(void* ev);
 int gf_event_record(gf_model* m, void* ev);
 int gf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);  /* synchronises on ev_stop */
 
+/* ---- device-resident ensemble sampler ------------------------------------------------------ */
+/* The emcee step either side of the path (golemflavor/mcmc.py:29-49: EnsembleSampler.sample / reset /
+ * chain / acceptance_fraction), run entirely on the device: `nchains` independent ensembles of `nwalkers`
+ * walkers of the model's posterior, affine-invariant stretch move (scale `a`, emcee's default 2.0),
+ * Philox4x32-10 keyed by `seed`.  One launch per half-ensemble update; the host sees chains at the end. */
+typedef struct gf_sampler gf_sampler;
+int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out);
+void gf_sampler_destroy(gf_sampler* s);
+/* p0 [nchains][nwalkers][ndim]; evaluates its lnprob on the device (mcmc.py:34 sampler.sample(p0, ...)) */
+int gf_sampler_set_state(gf_sampler* s, const double* pos);
+/* nsteps stretch-move steps, asynchronous; store != 0 appends every thin-th step to the device chain */
+int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store);
+int gf_sampler_sync(gf_sampler* s);
+/* clears the stored chain and the acceptance counters, keeps the walkers (mcmc.py:36 sampler.reset()) */
+int gf_sampler_reset(gf_sampler* s);
+int64_t gf_sampler_nstored(const gf_sampler* s);
+int64_t gf_sampler_iterations(const gf_sampler* s);
+int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob);
+/* chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
+ * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on; NULL = skip */
+int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only
  * exchanges are the broadcast of the packed descriptors at start and the gather of the chain blocks

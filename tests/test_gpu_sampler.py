@@ -1,0 +1,174 @@
+"""GPU: the device-resident stretch-move sampler (gf_sampler_*)."""
+import numpy as np
+import pytest
+
+from common import BIN_EDGES, bsm_args, notebook_sets, uniform_theta
+from golemflavor_amd import _lib
+from golemflavor_amd import configs as Cf
+from golemflavor_amd import llh as llh_utils
+from golemflavor_amd import mcmc as mcmc_utils
+from golemflavor_amd.enums import Texture
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0):
+    """The published stretch move, written out in numpy with the sampler's random stream: one
+    Philox4x32-10 block per (walker slot, half-step), u1 53 bits, partner and u3 32 bits."""
+    nchains, nwalkers, ndim = p0.shape
+    nhalf = nwalkers // 2
+    pos = p0.copy()
+    lnp = np.stack([oracle.lnprob_batch(om, pos[c]) for c in range(nchains)])
+    chain = np.empty((nchains, nsteps, nwalkers, ndim))
+    nacc = np.zeros((nchains, nwalkers), dtype=int)
+    key = (seed & 0xffffffff, seed >> 32)
+    for it in range(nsteps):
+        for half in (0, 1):
+            t = 2 * it + half
+            cbase = (1 - half) * nhalf
+            newpos, newlnp = pos.copy(), lnp.copy()
+            for c in range(nchains):
+                q = np.empty((nhalf, ndim)); zz = np.empty(nhalf); u3 = np.empty(nhalf)
+                for k in range(nhalf):
+                    g = c * nhalf + k
+                    r = oracle.philox4x32_10((g & 0xffffffff, g >> 32, t & 0xffffffff, t >> 32), key)
+                    u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
+                    j = (r[2] * nhalf) >> 32
+                    u3[k] = (r[3] + 0.5) / 4294967296.0
+                    zr = (a - 1.0) * u1 + 1.0
+                    zz[k] = zr * zr / a
+                    cj, sk = pos[c, cbase + j], pos[c, half * nhalf + k]
+                    q[k] = cj - zz[k] * (cj - sk)
+                lq = oracle.lnprob_batch(om, q)
+                lk = lnp[c, half * nhalf:(half + 1) * nhalf]
+                with np.errstate(all="ignore"):
+                    acc = np.log(zz ** (ndim - 1) / u3) > lk - lq
+                idx = np.arange(half * nhalf, (half + 1) * nhalf)[acc]
+                newpos[c, idx] = q[acc]
+                newlnp[c, idx] = lq[acc]
+                nacc[c, idx] += 1
+            pos, lnp = newpos, newlnp
+        chain[:, it] = pos
+    return chain, lnp, nacc
+
+
+def test_device_sampler_equals_reference_stretch_move(golden, oracle):
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=golden["g6_bestfit_fr"], smearing=0.02)
+    rng = np.random.default_rng(3)
+    nchains, nwalkers, nsteps, seed = 2, 32, 12, 0x1234567890ABCDEF
+    p0 = np.stack([uniform_theta(ps, nwalkers, rng, seeds=True) for _ in range(nchains)])
+    s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=seed)
+    s.run_mcmc(p0, nsteps)
+    ref_chain, ref_lnp, ref_acc = _reference_stretch(oracle, om, p0, nsteps, seed)
+    got = s.chain.transpose(0, 2, 1, 3)                       # -> (chain, step, walker, dim)
+    assert got.shape == ref_chain.shape
+    assert np.abs(got - ref_chain).max() < 1e-12              # same accept decisions, same proposals
+    assert np.array_equal(np.round(s.acceptance_fraction * nsteps).astype(int), ref_acc)
+    assert 0.15 < ref_acc.mean() / nsteps < 0.8
+    pos, lnp = s.state
+    assert np.allclose(lnp, ref_lnp, rtol=1e-12)
+    # reproducible: same seed, same chain; another seed, another chain
+    s2 = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=seed)
+    s2.run_mcmc(p0, nsteps)
+    assert np.array_equal(s2.chain, s.chain)
+    s3 = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=seed + 1)
+    s3.run_mcmc(p0, nsteps)
+    assert not np.array_equal(s3.chain, s.chain)
+    for x in (s, s2, s3):
+        x.close()
+    f.close()
+
+
+def test_device_sampler_bookkeeping_and_reset(golden):
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    np.random.seed(26)
+    p0 = mcmc_utils.flat_seed(ps, nwalkers=128)
+    s = mcmc_utils.DeviceEnsembleSampler(128, 6, f, seed=7)
+    s.run_mcmc(p0, 50)
+    assert s.iterations == 50 and s.chain.shape == (128, 50, 6)
+    s.reset()
+    assert s.iterations == 0 and s.chain.shape == (128, 0, 6)
+    s.run_mcmc(None, 300, thin=3)                              # continues from the burnt-in walkers
+    ch, lp = s.chain, s.lnprobability
+    assert ch.shape == (128, 100, 6) and lp.shape == (128, 100) and s.iterations == 300
+    # the stored lnprob is the kernel's own evaluation of the stored position, bit for bit
+    again = f.model.lnprob(ch.reshape(-1, 6), want_status=False).reshape(128, 100)
+    assert np.array_equal(again, lp)
+    # walkers never leave the prior box, -inf is never accepted
+    box = np.array(ps.ranges, dtype=float)
+    assert np.all(ch >= box[:, 0]) and np.all(ch <= box[:, 1]) and np.all(np.isfinite(lp))
+    acc = s.acceptance_fraction
+    assert acc.shape == (128,) and 0.3 < acc.mean() < 0.55
+    s.close()
+    f.close()
+
+
+def test_device_sampler_recovers_truncated_gaussian_priors():
+    """PRIOR_ONLY posterior of the 12-dim paramset = product of (truncated) Gaussians and boxes with
+    known moments (scripts/fr.py:30-58)."""
+    _, ps = Cf.fr_paramsets(6, (0.4444, 0.0))
+    f = llh_utils.prior_ln_prob(ps)
+    np.random.seed(1)
+    p0 = np.stack([mcmc_utils.flat_seed(ps, 256) for _ in range(4)])
+    s = mcmc_utils.DeviceEnsembleSampler(256, 12, f, nchains=4, seed=99)
+    s.run_mcmc(p0, 600, storechain=False)
+    s.run_mcmc(None, 1500, thin=5)
+    flat = s.flatchain.reshape(-1, 12)
+    names = list(ps.names)
+    for name, mu, sig in (("s_12_2", 0.307, 0.013), ("c_13_4", (1 - 0.02206) ** 2, 0.00147), ("m21_2", 7.40e-23, 2.1e-24),
+                          ("m3x_2", 2.494e-21, 3.3e-23), ("convNorm", 1.0, 0.4)):
+        x = flat[:, names.index(name)]
+        assert x.mean() == pytest.approx(mu, abs=0.08 * sig + 1e-30), name
+        assert x.std() == pytest.approx(sig, rel=0.08), name
+    # uniform columns fill their box: dcp ~ U(0, 2pi), logLam ~ U(-56, -30)
+    d = flat[:, names.index("dcp")]
+    assert d.mean() == pytest.approx(np.pi, abs=0.15) and d.std() == pytest.approx(2 * np.pi / np.sqrt(12), rel=0.08)
+    ll = flat[:, names.index("logLam")]
+    assert ll.min() >= -56 and ll.max() <= -30 and ll.std() == pytest.approx(26 / np.sqrt(12), rel=0.1)
+    s.close()
+    f.close()
+
+
+def test_mcmc_driver_device_resident(golden, capsys):
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    np.random.seed(26)
+    p0 = mcmc_utils.flat_seed(ps, nwalkers=100)
+    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500, device_resident=True, seed=5)
+    out = capsys.readouterr().out
+    assert samples.shape == (100 * 1500, 6)
+    acc = float(out.split("sum of acceptance fraction")[1].split()[0]) / 100
+    assert 0.36 < acc < 0.50                                   # reference notebook: 0.427
+    assert f.ncalls == 0                                       # no host-driven evaluations at all
+    # same posterior as the host-driven sampler
+    np.random.seed(26)
+    host = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500)
+    capsys.readouterr()
+    for d in range(6):
+        sd = host[:, d].std()
+        assert abs(samples[:, d].mean() - host[:, d].mean()) < 0.25 * sd
+        assert samples[:, d].std() == pytest.approx(sd, rel=0.2)
+    f.close()
+
+
+def test_device_sampler_bsm_posterior():
+    asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
+    args = bsm_args(6, Texture.OET, (0., 1., 0.))
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.05, on_nonunitary="-inf")
+    rng = np.random.default_rng(2)
+    p0 = uniform_theta(ps, 64, rng, seeds=True)
+    p0[:, 11] = rng.uniform(-52, -46, 64)
+    s = mcmc_utils.DeviceEnsembleSampler(64, 12, f, seed=11)
+    s.run_mcmc(p0, 40)
+    ch, lp = s.chain, s.lnprobability
+    again = f.model.lnprob(ch.reshape(-1, 12), want_status=False).reshape(64, 40)
+    fin = np.isfinite(lp)
+    assert np.array_equal(again[fin], lp[fin])
+    box = np.array(ps.ranges, dtype=float)
+    assert np.all(ch >= box[:, 0]) and np.all(ch <= box[:, 1])
+    assert 0.02 < s.acceptance_fraction.mean() < 0.9
+    s.close()
+    f.close()

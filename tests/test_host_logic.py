@@ -107,8 +107,8 @@ def test_compile_model_bsm_rules():
 # ---------------------------------------------------------------- C ABI (no compute calls: no GPU here)
 def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "golemflavor_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(gf_[a-z0-9_]+)\s*\(", hdr, re.M))
-    assert len(declared) >= 29
+    declared = set(re.findall(r"^(?:int|void|size_t|int64_t|const char\*)\s+(gf_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert len(declared) >= 39
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), "libgolemhip.so does not export %s" % name
