@@ -237,6 +237,25 @@ def main():
             out["rccl_gather_ok"] = gathered_ok
         if rccl_error is not None:
             out["rccl_error"] = rccl_error
+        if world == 1:
+            # emcee-driven figure (not `value`): one 4096-walker ensemble advanced by the device-resident
+            # stretch-move sampler, 2 launches per step, walkers never leave HBM
+            try:
+                from golemflavor_amd import mcmc as mcmc_utils
+                rngp = np.random.default_rng(26)
+                box = np.array(ps.seeds, dtype=np.float64)
+                p0 = rngp.uniform(box[:, 0], box[:, 1], size=(a.walkers, 6))
+                smp = mcmc_utils.DeviceEnsembleSampler(a.walkers, 6, model, seed=26)
+                smp.run_mcmc(p0, 50, storechain=False)
+                t0 = time.perf_counter()
+                smp.run_mcmc(None, 500, storechain=False)
+                dt = time.perf_counter() - t0
+                out["emcee_driven"] = {"sampler": "device-resident stretch move", "walkers": a.walkers, "chains": 1,
+                                       "steps": 500, "us_per_step": 1e6 * dt / 500, "evals_per_s": a.walkers * 500 / dt,
+                                       "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
+                smp.close()
+            except Exception as exc:       # noqa: BLE001
+                out["emcee_driven"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not a.no_cpu_baseline:
             cb, ref = cpu_baseline(ps, bf, theta, a.cpu_sample)
             got = d_out.download((len(ref),))
