@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 
 #include "../../include/golemflavor_hip.h"
@@ -46,20 +47,37 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Step counters live on the device so that a captured hipGraph of GRAPH_STEPS steps can be replayed with
+// constant kernel arguments: each kernel node carries its own frozen `step_offset`; the base counters
+// are advanced once per replay by k_tick (one extra 1-thread launch per GRAPH_STEPS steps).
+struct StepState {
+    uint64_t iteration_base;  // Philox counter word of step_offset 0
+    int64_t run_step_base;    // steps of the current gf_sampler_run call done before step_offset 0
+    int64_t store_base;       // chain slot of the run's first stored step
+    int32_t store;            // this run stores at all
+    int32_t thin;
+};
+
 struct StretchArgs {
+    StepState* state;
     double* pos;            // [nchains][nwalkers][ndim]
     double* lnp;            // [nchains][nwalkers]
     uint32_t* naccept;      // [nchains][nwalkers]
     uint32_t* flags;        // [0]: walkers whose proposal came back NON_UNITARY (reference would raise)
     double* chain;          // [nchains][nstore_cap][nwalkers][ndim] or null
     double* lnp_chain;      // [nchains][nstore_cap][nwalkers] or null
-    int64_t store_index;    // slot to write this step into (ignored when chain == null)
     int64_t nstore_cap;
     uint64_t seed;
-    uint64_t iteration;
     int32_t nchains, nwalkers, half;
+    int32_t step_offset;    // step index relative to the device-side base counters
     double a;
 };
+
+__global__ void k_tick(StepState* st, int nsteps)
+{
+    st->iteration_base += (uint64_t)nsteps;
+    st->run_step_base += nsteps;
+}
 
 // lnprob of the proposal held in LDS row `row`
 template <int NDIM, int MODE>
@@ -107,18 +125,23 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int wave = threadIdx.x / GF_WAVE;
     double* row = tiles[wave] + lane * ndim;
+    const uint64_t iteration = s.state->iteration_base + (uint64_t)s.step_offset;
+    const int64_t run_step = s.state->run_step_base + s.step_offset;
+    const int thin = s.state->thin;
+    const bool store_now = s.state->store != 0 && s.chain != nullptr && (run_step % thin) == 0;
+    const int64_t store_index = s.state->store_base + (run_step + thin - 1) / thin;   // stored steps before this one
     const int nhalf = s.nwalkers / 2;
     const int64_t total = (int64_t)s.nchains * nhalf;
     const int64_t g = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
-    if (g >= total) return;
+    if (g < total) {
     const int chain = (int)(g / nhalf);
     const int k = (int)(g - (int64_t)chain * nhalf);
     const int w = s.half * nhalf + k;                        // this walker, in the active half
     const int cbase = (1 - s.half) * nhalf;                  // complementary half
 
     uint32_t r[4];
-    philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(2 * s.iteration + s.half),
-                 (uint32_t)((2 * s.iteration + s.half) >> 32), (uint32_t)s.seed, (uint32_t)(s.seed >> 32), r);
+    philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(2 * iteration + s.half),
+                 (uint32_t)((2 * iteration + s.half) >> 32), (uint32_t)s.seed, (uint32_t)(s.seed >> 32), r);
     const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
     const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
     const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
@@ -156,16 +179,17 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const
         s.lnp[wi] = lnq;
         s.naccept[wi] += 1u;
     }
-    if (s.chain) {
-        double* dst = s.chain + (((int64_t)chain * s.nstore_cap + s.store_index) * s.nwalkers + w) * ndim;
+    if (store_now) {
+        double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w) * ndim;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             if (!NDIM && d >= ndim) break;
             dst[d] = accept ? row[d] : sk[d];
         }
         if (s.lnp_chain)
-            s.lnp_chain[((int64_t)chain * s.nstore_cap + s.store_index) * s.nwalkers + w] = accept ? lnq : lnk;
+            s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
     }
+    }   // g < total
 }
 
 template <int NDIM>
@@ -208,6 +232,11 @@ struct gf_sampler {
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
     int64_t steps_since_reset = 0;
+    StepState* d_state = nullptr;
+    // captured graph of GRAPH_STEPS steps (2 nodes per step + one tick), valid for the chain pointers it was built with
+    hipGraphExec_t graph = nullptr;
+    double* graph_chain = nullptr;
+    int graph_has_chain = -1;
 };
 
 // accessors implemented in gf_capi.hip (gf_model is private to it)
@@ -250,6 +279,8 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_lnp, sizeof(double) * nw);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_naccept, sizeof(uint32_t) * nw);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, sizeof(uint32_t) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_state, sizeof(StepState));
+    if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(StepState));
     if (e == hipSuccess) e = hipMemset(s->d_naccept, 0, sizeof(uint32_t) * nw);
     if (e == hipSuccess) e = hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4);
     if (e != hipSuccess) { int rc = sfail(e, "gf_sampler_create"); gf_sampler_destroy(s); return rc; }
@@ -269,6 +300,8 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_lnp) (void)hipFree(s->d_lnp);
     if (s->d_naccept) (void)hipFree(s->d_naccept);
     if (s->d_flags) (void)hipFree(s->d_flags);
+    if (s->d_state) (void)hipFree(s->d_state);
+    if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
     delete s;
@@ -337,24 +370,69 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             s->d_chain = nc; s->d_lnp_chain = nl; s->nstore_cap = cap;
         }
     }
+    // device-side step counters for this run
+    StepState hs;
+    hs.iteration_base = s->iteration; hs.run_step_base = 0; hs.store_base = s->nstored;
+    hs.store = store ? 1 : 0; hs.thin = thin;
+    GFS_HIP(hipStreamSynchronize(st));          // earlier runs must be done with the counters
+    GFS_HIP(hipMemcpy(s->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     StretchArgs a;
+    a.state = s->d_state;
     a.pos = s->d_pos; a.lnp = s->d_lnp; a.naccept = s->d_naccept; a.flags = s->d_flags;
+    a.chain = store ? s->d_chain : nullptr;
+    a.lnp_chain = store ? s->d_lnp_chain : nullptr;
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
-    for (int64_t i = 0; i < nsteps; ++i) {
-        const bool keep = store && (i % thin == 0);
-        a.chain = keep ? s->d_chain : nullptr;
-        a.lnp_chain = keep ? s->d_lnp_chain : nullptr;
-        a.store_index = s->nstored;
-        a.iteration = s->iteration;
-        for (int half = 0; half < 2; ++half) {
-            a.half = half;
-            hipError_t e = launch_stretch(*c, tb, ptab, a, st);
-            if (e != hipSuccess) return sfail(e, "stretch launch");
+    auto steps = [&](int count) -> hipError_t {       // `count` steps relative to the current base, then tick
+        for (int i = 0; i < count; ++i) {
+            a.step_offset = i;
+            for (int half = 0; half < 2; ++half) {
+                a.half = half;
+                hipError_t e = launch_stretch(*c, tb, ptab, a, st);
+                if (e != hipSuccess) return e;
+            }
         }
-        s->iteration += 1;
-        s->steps_since_reset += 1;
-        if (keep) s->nstored += 1;
+        hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, s->d_state, count);
+        return hipGetLastError();
+    };
+    constexpr int GRAPH_STEPS = 16;
+    int64_t done = 0;
+    static const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;   // diagnostics
+    if (!no_graph && nsteps >= 2 * GRAPH_STEPS) {
+        // launch-bound inner loop -> hipGraph: capture GRAPH_STEPS steps once, replay
+        if (!s->graph || s->graph_chain != a.chain || s->graph_has_chain != (store ? 1 : 0)) {
+            if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                e = steps(GRAPH_STEPS);
+                hipError_t e2 = hipStreamEndCapture(st, &g);
+                if (e == hipSuccess) e = e2;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {                      // graphs unavailable: fall through to eager launches
+                (void)hipGetLastError();
+                s->graph = nullptr;
+            } else {
+                s->graph_chain = a.chain;
+                s->graph_has_chain = store ? 1 : 0;
+            }
+        }
+        while (s->graph && nsteps - done >= GRAPH_STEPS) {
+            hipError_t e = hipGraphLaunch(s->graph, st);
+            if (e != hipSuccess) return sfail(e, "hipGraphLaunch");
+            done += GRAPH_STEPS;
+        }
     }
+    while (done < nsteps) {
+        const int count = (int)((nsteps - done < 64) ? (nsteps - done) : 64);
+        hipError_t e = steps(count);
+        if (e != hipSuccess) return sfail(e, "stretch launch");
+        done += count;
+    }
+    s->iteration += (uint64_t)nsteps;
+    s->steps_since_reset += nsteps;
+    if (store) s->nstored += (nsteps + thin - 1) / thin;
     return GF_OK;
 }
 

@@ -12,7 +12,7 @@ def main():
     ang = fr_utils.fr_to_angles(fr_utils.u_to_fr((1, 0, 0), fr_utils.NUFIT_U))
     asimov, ps = Cf.notebook_paramsets(ang)
     f = llh_utils.notebook_ln_prob(asimov, ps)
-    for nwalkers, nchains, nsteps in ((100, 1, 2000), (4096, 1, 2000), (4096, 16, 1000), (4096, 256, 200), (2048, 64, 500)):
+    for nwalkers, nchains, nsteps in ((100, 1, 2000), (4096, 1, 2000), (4096, 16, 1000), (4096, 64, 400), (4096, 256, 200), (2048, 64, 500)):
         np.random.seed(26)
         p0 = np.stack([mcmc_utils.flat_seed(ps, nwalkers) for _ in range(nchains)])
         s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=1)
