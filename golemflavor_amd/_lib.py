@@ -74,6 +74,8 @@ SIGNATURES = {
     "gf_lnprob_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, _vp]),
     "gf_propagate_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
     "gf_haar_draw_device": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]),
+    "gf_flavor_histogram_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
+    "gf_flavor_histogram": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]),
     "gf_model_sync": (C.c_int, [_vp]),
     "gf_event_create": (C.c_int, [C.POINTER(_vp)]),
     "gf_event_destroy": (C.c_int, [_vp]),
@@ -89,6 +91,7 @@ SIGNATURES = {
     "gf_sampler_iterations": (C.c_int64, [_vp]),
     "gf_sampler_get_state": (C.c_int, [_vp, _dp, _dp]),
     "gf_sampler_get_chain": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gf_sampler_postprocess": (C.c_int, [_vp, _dp, _ip, C.c_int, C.POINTER(C.c_uint64)]),
     "gf_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "gf_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gf_comm_destroy": (None, [_vp]),

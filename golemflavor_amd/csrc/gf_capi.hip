@@ -489,6 +489,43 @@ int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t 
     return GF_OK;
 }
 
+// counts[nb][nb][nb] += histogram of n compositions resident on the device (asynchronous)
+int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int nbins, uint64_t* d_counts)
+{
+    if (!m || n < 0 || nbins < 1 || nbins > 1024) return GF_ERR_INVALID_ARG;
+    if (n == 0) return GF_OK;
+    int rc = check_dev_ptr(d_fr, 8);
+    if (rc == GF_OK) rc = check_dev_ptr(d_counts, 8);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipSetDevice(m->device));
+    hipError_t e = gf_launch_flavor_hist(d_fr, n, nbins, (unsigned long long*)d_counts, m->cus, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "histogram launch");
+    return GF_OK;
+}
+
+// host convenience: fr [n][3] -> counts [nbins]^3 (zeroed first)
+int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uint64_t* counts)
+{
+    if (!m || n < 0 || (n > 0 && !fr) || !counts || nbins < 1 || nbins > 1024) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    const size_t nbin3 = (size_t)nbins * nbins * nbins;
+    double* d_fr = nullptr;
+    uint64_t* d_c = nullptr;
+    GF_HIP(hipMalloc((void**)&d_c, sizeof(uint64_t) * nbin3));
+    hipError_t e = hipMemsetAsync(d_c, 0, sizeof(uint64_t) * nbin3, m->stream);
+    if (e == hipSuccess && n > 0) e = hipMalloc((void**)&d_fr, sizeof(double) * 3 * n);
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(d_fr, fr, sizeof(double) * 3 * n, hipMemcpyHostToDevice, m->stream);
+    int rc = GF_OK;
+    if (e == hipSuccess && n > 0) rc = gf_flavor_histogram_device(m, d_fr, n, nbins, d_c);
+    if (e == hipSuccess && rc == GF_OK) e = hipMemcpyAsync(counts, d_c, sizeof(uint64_t) * nbin3, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (d_fr) (void)hipFree(d_fr);
+    (void)hipFree(d_c);
+    if (rc != GF_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "gf_flavor_histogram");
+    return GF_OK;
+}
+
 int gf_model_sync(gf_model* m)
 {
     if (!m) return GF_ERR_INVALID_ARG;

@@ -247,6 +247,28 @@ __global__ __launch_bounds__(GF_BLOCK) void k_haar(const GfCommon c, uint64_t se
     }
 }
 
+// Flavor-triangle histogram of a block of compositions: the reduction golemflavor/plot.py:365-370 does
+// with np.histogramdd(frs, bins=(nb, nb, nb), range=((0,1),)*3): nb equal bins per axis on [0, 1], the
+// last bin closed on the right, samples outside the cube (or NaN) dropped.  counts is [nb][nb][nb].
+__global__ __launch_bounds__(GF_BLOCK) void k_flavor_hist(const double* __restrict__ fr, int64_t n, int nb,
+                                                          unsigned long long* __restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * GF_BLOCK;
+    const double scale = (double)nb;
+    for (int64_t i = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x; i < n; i += stride) {
+        int idx[3];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = fr[3 * i + a];
+            ok = ok && (v >= 0.0) && (v <= 1.0);
+            int b = (int)(v * scale);
+            idx[a] = b >= nb ? nb - 1 : b;
+        }
+        if (ok) atomicAdd(counts + ((int64_t)idx[0] * nb + idx[1]) * nb + idx[2], 1ull);
+    }
+}
+
 #ifndef GF_BLOCKS_PER_CU
 #define GF_BLOCKS_PER_CU 8
 #endif
@@ -328,6 +350,13 @@ hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int la
     case 6: return launch_propagate_sm_n<6>(c, theta, layout, n, fr, status, cus, s);
     default: return launch_propagate_sm_n<0>(c, theta, layout, n, fr, status, cus, s);
     }
+}
+
+hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s)
+{
+    const int grid = grid_for(n, GF_BLOCK, cus);
+    hipLaunchKernelGGL(k_flavor_hist, dim3(grid), dim3(GF_BLOCK), 0, s, fr, n, nb, counts);
+    return hipGetLastError();
 }
 
 hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,

@@ -478,4 +478,47 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
     return GF_OK;
 }
 
+// Chain post-processing on the device (scripts/mc_unitary.py:189-193, mc_texture.py:216-221, and the
+// histogram of golemflavor/plot.py:365-370): measured composition of every stored sample, optionally
+// reduced to the [nbins]^3 flavor histogram so that only the counts cross PCIe.
+//   fr      [nchains][nstored][nwalkers][3]  or NULL
+//   status  [nchains][nstored][nwalkers]     or NULL
+//   counts  [nchains][nbins][nbins][nbins]   or NULL (nbins ignored then)
+int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts)
+{
+    if (!s || (counts && (nbins < 1 || nbins > 1024))) return GF_ERR_INVALID_ARG;
+    int rc = gf_model_sync(s->model);
+    if (rc != GF_OK || s->nstored == 0) return rc;
+    const int64_t per_chain = s->nstored * s->nwalkers;
+    const size_t nbin3 = counts ? (size_t)nbins * nbins * nbins : 0;
+    double* d_fr = nullptr;
+    int32_t* d_st = nullptr;
+    uint64_t* d_c = nullptr;
+    GFS_HIP(hipMalloc((void**)&d_fr, sizeof(double) * 3 * per_chain));
+    hipError_t e = hipSuccess;
+    if (status) e = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain);
+    if (e == hipSuccess && counts) e = hipMalloc((void**)&d_c, sizeof(uint64_t) * nbin3);
+    for (int ch = 0; ch < s->nchains && e == hipSuccess && rc == GF_OK; ++ch) {
+        const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
+        rc = gf_propagate_batch_device(s->model, d_theta, GF_LAYOUT_AOS, per_chain, d_fr, d_st);
+        if (rc != GF_OK) break;
+        if (counts) {
+            e = hipMemset(d_c, 0, sizeof(uint64_t) * nbin3);      // null stream: ordered after the sync below
+            if (e == hipSuccess) rc = gf_model_sync(s->model);
+            if (e == hipSuccess && rc == GF_OK) rc = gf_flavor_histogram_device(s->model, d_fr, per_chain, nbins, d_c);
+        }
+        if (rc == GF_OK) rc = gf_model_sync(s->model);
+        if (rc != GF_OK) break;
+        if (fr) e = hipMemcpy(fr + (size_t)ch * per_chain * 3, d_fr, sizeof(double) * 3 * per_chain, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && status) e = hipMemcpy(status + (size_t)ch * per_chain, d_st, sizeof(int32_t) * per_chain, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && counts) e = hipMemcpy(counts + (size_t)ch * nbin3, d_c, sizeof(uint64_t) * nbin3, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_fr);
+    if (d_st) (void)hipFree(d_st);
+    if (d_c) (void)hipFree(d_c);
+    if (rc != GF_OK) return rc;
+    if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess");
+    return GF_OK;
+}
+
 }  // extern "C"

@@ -16,7 +16,7 @@ from .descriptor import compile_model
 from .enums import ParamTag, Texture
 from .model import Model
 
-__all__ = ["LnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior"]
+__all__ = ["LnProb", "CubeLnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior"]
 
 
 class LnProb:
@@ -87,3 +87,35 @@ def lnprior(theta, paramset, device=0):
         return f(theta)
     finally:
         f.close()
+
+
+class CubeLnProb:
+    """MultiNest-style callback adapter (golemflavor/mn.py:26-45 `lnProb(cube, ndim, n_params, ...)`).
+
+    `mn_paramset` is the scanned subset of `llh_paramset`; the unit cube is mapped onto its ranges,
+    theta_i = (hi_i - lo_i) * cube_i + lo_i (mn.py:35-36), the other columns keep their current
+    `.value`, and the batch goes to the GPU in one launch: a nested sampler can hand over all its
+    live-point proposals at once (`cube` of shape (n, ndim)) or one point (shape (ndim,)), as
+    MultiNest does.
+    """
+
+    def __init__(self, ln_prob, mn_paramset, llh_paramset):
+        self.ln_prob = ln_prob
+        names = list(llh_paramset.names)
+        self.cols = np.array([names.index(n) for n in mn_paramset.names], dtype=np.intp)
+        rng = np.array(mn_paramset.ranges, dtype=np.float64)
+        self.lo, self.span = rng[:, 0], rng[:, 1] - rng[:, 0]
+        self.base = np.array(llh_paramset.values, dtype=np.float64)
+        self.ndim = len(self.cols)
+
+    def __call__(self, cube, ndim=None, n_params=None):
+        if ndim is not None and ndim != self.ndim:
+            raise AssertionError("Length of MultiNest scan paramset is not the same as the input params")
+        u = np.asarray([cube[i] for i in range(self.ndim)], dtype=np.float64) if np.ndim(cube) <= 1 and not \
+            isinstance(cube, np.ndarray) else np.asarray(cube, dtype=np.float64)
+        single = u.ndim == 1
+        u = np.atleast_2d(u)[:, :self.ndim]
+        theta = np.tile(self.base, (u.shape[0], 1))
+        theta[:, self.cols] = self.span * u + self.lo
+        out = self.ln_prob(theta)
+        return float(out[0]) if single else out

@@ -17,6 +17,7 @@ Sampler parity: the reference never seeds emcee's RNG and holds no test of sampl
 chains cannot be compared sample by sample ("sampler parity unpinned"); tests
 check the move's invariants and the reference notebook's acceptance fraction / autocorrelation.
 """
+import math
 import os
 import sys
 
@@ -310,6 +311,31 @@ class DeviceEnsembleSampler:
         nacc = self._fetch()[2].astype(np.float64) / max(self.iterations, 1)
         return nacc[0] if self.nchains == 1 else nacc
 
+    def postprocess(self, want_fr=True, want_status=False, nbins=None):
+        """Chain post-processing on the device: the measured composition of every stored sample
+        (scripts/mc_unitary.py:189-193, mc_texture.py:216-221) and/or its flavor histogram
+        (golemflavor/plot.py:365-370).  Returns a dict with 'fr' (nwalkers, nsteps, 3), 'status',
+        'hist' (nbins, nbins, nbins) -- each with a leading chain axis when nchains > 1."""
+        C = self._C
+        ns = int(self._L.gf_sampler_nstored(self._h))
+        fr = np.empty((self.nchains, ns, self.k, 3)) if want_fr else None
+        st = np.empty((self.nchains, ns, self.k), dtype=np.int32) if want_status else None
+        hist = np.zeros((self.nchains, nbins, nbins, nbins), dtype=np.uint64) if nbins else None
+        self._lib.check(self._L.gf_sampler_postprocess(
+            self._h, fr.ctypes.data_as(self._lib._dp) if want_fr else None,
+            st.ctypes.data_as(self._lib._ip) if want_status else None, int(nbins or 0),
+            hist.ctypes.data_as(C.POINTER(C.c_uint64)) if nbins else None), "gf_sampler_postprocess")
+        out = {}
+        if want_fr:
+            f = np.ascontiguousarray(fr.transpose(0, 2, 1, 3))
+            out["fr"] = f[0] if self.nchains == 1 else f
+        if want_status:
+            t = np.ascontiguousarray(st.transpose(0, 2, 1))
+            out["status"] = t[0] if self.nchains == 1 else t
+        if nbins:
+            out["hist"] = hist[0] if self.nchains == 1 else hist
+        return out
+
     @property
     def acor(self):
         return self.get_autocorr_time()
@@ -385,6 +411,39 @@ def mcmc_argparse(parser):
                         help='Plot MCMC triangle in the angles space')
     parser.add_argument('--plot-elements', type=parse_bool, default='False',
                         help='Plot MCMC triangle in the mixing elements space')
+
+
+def solve_ratio(fr):
+    """'1_2_0' for small-integer ratios, else two-decimal floats (golemflavor/misc.py:34-41; the reference
+    reduces with a floating-point gcd, restated here with a tolerance)."""
+    fr = [float(x) for x in fr]
+
+    def fgcd(a, b):
+        while abs(b) > 1e-9:
+            a, b = b, a % b
+        return a
+    den = 0.0
+    for x in fr:
+        den = fgcd(den, x) if den else x
+    f = [int(round(x / den)) if den else 0 for x in fr]
+    if any(v not in (1, 2, 0) for v in f) or any(abs(x / den - v) > 1e-6 for x, v in zip(fr, f)):
+        return '{0:.2f}_{1:.2f}_{2:.2f}'.format(*fr)
+    return '{0}_{1}_{2}'.format(*f)
+
+
+def chain_identifier(args):
+    """File-name stem of the reference's chain files so that its plotting scripts find ours
+    (golemflavor/misc.py:44-51 gen_identifier): `_DIM{d}_sfr_{..}[_mfr_{..}][_{texture}]`; `_mfr_` only for
+    injected (Asimov / realisation) data."""
+    stem = '_DIM{0}'.format(args.dimension)
+    stem += '_sfr_' + solve_ratio(args.source_ratio)
+    data = getattr(getattr(args, "data", None), "name", None)
+    if data in ("ASIMOV", "REALISATION") or (data is None and getattr(args, "injected_ratio", None) is not None):
+        stem += '_mfr_' + solve_ratio(args.injected_ratio)
+    tex = getattr(args, "texture", None)
+    if tex is not None and getattr(tex, "name", "NONE") != "NONE":
+        stem += '_{0}'.format(tex.name)
+    return stem
 
 
 def flat_seed(paramset, nwalkers):

@@ -133,6 +133,14 @@ class Model:
                                    fr.ctypes.data_as(_lib._dp)), "gf_haar_draw")
         return (fr, ang) if want_angles else fr
 
+    def flavor_histogram(self, fr, nbins):
+        """np.histogramdd(fr, bins=(nbins,)*3, range=((0,1),)*3)[0] on the GPU (golemflavor/plot.py:365-370)."""
+        f = np.ascontiguousarray(fr, dtype=np.float64).reshape(-1, 3)
+        counts = np.zeros((nbins, nbins, nbins), dtype=np.uint64)
+        check(self._L.gf_flavor_histogram(self._h, f.ctypes.data_as(_lib._dp), f.shape[0], int(nbins),
+                                          counts.ctypes.data_as(C.POINTER(C.c_uint64))), "gf_flavor_histogram")
+        return counts
+
     # -- device-resident path ----------------------------------------------------------
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

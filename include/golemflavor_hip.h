@@ -154,6 +154,11 @@ int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, in
                               double* d_fr, int32_t* d_status);
 int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n,
                         double* d_angles, double* d_fr);
+/* Flavor-triangle histogram (golemflavor/plot.py:365-370, np.histogramdd on [0,1]^3 with `nbins` bins per
+ * axis, last bin closed): counts[nbins][nbins][nbins] += ... ; the device variant is asynchronous and
+ * accumulates, the host variant zeroes first. */
+int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int nbins, uint64_t* d_counts);
+int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uint64_t* counts);
 int gf_model_sync(gf_model* m);
 
 /* HIP events on the model's stream (what bench.py times the kernel with) */
@@ -183,6 +188,11 @@ int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob);
 /* chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
  * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on; NULL = skip */
 int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary);
+/* Chain post-processing on the device (scripts/mc_unitary.py:189-193, scripts/mc_texture.py:216-221,
+ * golemflavor/plot.py:365-370): composition of every stored sample and/or its [nbins]^3 histogram per
+ * chain.  fr [nchains][nstored][nwalkers][3], status [nchains][nstored][nwalkers],
+ * counts [nchains][nbins]^3; NULL = skip. */
+int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only

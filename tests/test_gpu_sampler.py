@@ -172,3 +172,58 @@ def test_device_sampler_bsm_posterior():
     assert 0.02 < s.acceptance_fraction.mean() < 0.9
     s.close()
     f.close()
+
+
+def test_chain_postprocessing_on_device(golden, oracle):
+    """fr of every stored sample + the flavor histogram of plot.flavor_contour, without the chain crossing PCIe."""
+    ps = Cf.unitary_paramset()
+    src = np.array([1., 2., 0.]) / 3
+    from golemflavor_amd.descriptor import compile_model
+    from golemflavor_amd.model import Model
+    m = Model(compile_model(ps, "PRIOR_ONLY", source_ratio=src))
+    np.random.seed(3)
+    p0 = np.stack([mcmc_utils.flat_seed(ps, 64) for _ in range(2)])
+    s = mcmc_utils.DeviceEnsembleSampler(64, 4, m, nchains=2, seed=4)
+    s.run_mcmc(p0, 200, thin=2)
+    nb = 26
+    post = s.postprocess(want_fr=True, want_status=True, nbins=nb)
+    ch = s.chain                                                  # (2, 64, 100, 4)
+    assert post["fr"].shape == (2, 64, 100, 3) and post["hist"].shape == (2, nb, nb, nb)
+    om = oracle.make_model(ps, "PRIOR_ONLY", source_ratio=src)
+    ref_fr, _ = oracle.propagate_batch(om, ch.reshape(-1, 4))
+    assert np.abs(post["fr"].reshape(-1, 3) - ref_fr).max() < 1e-10      # mc_unitary.py:189-193
+    assert np.all(post["status"] == 0)
+    for c in range(2):
+        want, _ = np.histogramdd(post["fr"][c].reshape(-1, 3), bins=(nb, nb, nb), range=((0, 1),) * 3)
+        assert np.array_equal(post["hist"][c], want.astype(np.uint64))     # plot.py:365-370
+        assert post["hist"][c].sum() == 64 * 100
+    # stand-alone histogram entry point, edge cases: 1.0 lands in the last bin, outside / NaN dropped
+    pts = np.array([[0., 0., 1.], [1., 0., 0.], [0.5, 0.5, 0.], [1.0000001, 0., 0.], [-1e-9, .5, .5], [np.nan, .1, .9],
+                    [1 / 3, 1 / 3, 1 / 3]])
+    want, _ = np.histogramdd(pts[[0, 1, 2, 6]], bins=(5, 5, 5), range=((0, 1),) * 3)
+    assert np.array_equal(m.flavor_histogram(pts, 5), want.astype(np.uint64))
+    s.close()
+    m.close()
+
+
+def test_multinest_style_cube_adapter(golden):
+    """mn.py:26-45: unit cube -> scanned params, other columns fixed, batched."""
+    asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
+    args = bsm_args(6, Texture.OET, (0., 1., 0.))
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.05, on_nonunitary="-inf")
+    ps["logLam"].value = -50.0                                     # sens.py fixes the scale per evaluation
+    from golemflavor_amd.param import ParamSet
+    mn_ps = ParamSet([p for p in ps if p.name != "logLam"])
+    g = llh_utils.CubeLnProb(f, mn_ps, ps)
+    rng = np.random.default_rng(8)
+    cube = rng.uniform(0.3, 0.7, size=(50, 11))
+    out = g(cube)
+    lo = np.array(mn_ps.ranges)[:, 0]; hi = np.array(mn_ps.ranges)[:, 1]
+    theta = np.column_stack([(hi - lo) * cube + lo, np.full(50, -50.0)])
+    assert np.array_equal(out, f(theta))
+    assert g(list(cube[3]), 11, 11) == out[3]
+    with pytest.raises(AssertionError):
+        g(cube[0], 10, 10)
+    f.close()
+
+

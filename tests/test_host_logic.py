@@ -245,3 +245,17 @@ def test_integrated_time_on_ar1():
     assert tau == pytest.approx((1 + rho) / (1 - rho), rel=0.1)       # 19
     with pytest.raises(mcmc_utils.AutocorrError):
         mcmc_utils.integrated_time(x[:200, None])
+
+
+def test_chain_identifier_matches_reference_naming():
+    """misc.py:34-51 gen_identifier / solve_ratio."""
+    import argparse
+    from golemflavor_amd.enums import DataType
+    a = argparse.Namespace(dimension=6, source_ratio=np.array([1., 2., 0.]) / 3, injected_ratio=np.array([1., 1., 1.]) / 3,
+                           texture=Texture.OET, data=DataType.ASIMOV)
+    assert mcmc_utils.chain_identifier(a) == "_DIM6_sfr_1_2_0_mfr_1_1_1_OET"
+    a.data = DataType.REAL
+    a.texture = Texture.NONE
+    a.source_ratio = np.array([0.3, 0.7, 0.0])
+    assert mcmc_utils.chain_identifier(a) == "_DIM6_sfr_0.30_0.70_0.00"
+    assert mcmc_utils.solve_ratio([0., 1., 0.]) == "0_1_0" and mcmc_utils.solve_ratio([2., 4., 0.]) == "1_2_0"
