@@ -352,3 +352,57 @@ def test_full_size_properties(golden, nb_model):
     assert rel_err(a, b) <= 1e-12
     for buf in (d_th, d_out, d_fr):
         buf.free()
+
+
+# ---------------------------------------------------------------- maximum sizes of the descriptor
+def test_max_dim_16_columns(oracle):
+    """GF_MAX_DIM = 16 columns: 4 mixing + 2 source + 10 nuisance columns with mixed priors."""
+    tag = ParamTag.NUISANCE
+    extra = []
+    for i in range(10):
+        prior = [None, Cf.PriorsCateg.GAUSSIAN, Cf.PriorsCateg.LIMITEDGAUSS][i % 3]
+        extra.append(Param(name="nuis%d" % i, value=1.0 + 0.1 * i, ranges=[0., 3. + i], std=0.2 + 0.05 * i, prior=prior, tag=tag))
+    asimov, nb = Cf.notebook_paramsets((0.5373597586219514, 0.5006819093249053))
+    ps = ParamSet(list(nb) + extra)
+    assert len(ps) == 16
+    bf = (0.55, 0.18, 0.27)
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02)
+    rng = np.random.default_rng(16)
+    th = np.vstack([uniform_theta(ps, 3000, rng, seeds=True), uniform_theta(ps, 1000, rng, seeds=False)])
+    ref, ref_fr = oracle.lnprob_batch(om, th, want_fr=True)
+    with Model(compile_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02)) as m:
+        lp, fr, st = m.lnprob(th, want_fr=True)
+        d = m.alloc(th.nbytes).upload(np.ascontiguousarray(th.T))
+        o = m.alloc(8 * len(th))
+        m.lnprob_device(d.ptr, len(th), o.ptr, None, None, layout=GF_LAYOUT_SOA)
+        m.sync()
+        assert np.array_equal(o.download((len(th),)), lp, equal_nan=True)
+    assert np.array_equal(np.isinf(lp), np.isinf(ref)) and rel_err(lp, ref) <= REL
+    with pytest.raises(ValueError):
+        compile_model(ParamSet(list(ps) + [Param(name="one_too_many", value=0, ranges=[0, 1])]), "PRIOR_ONLY")
+
+
+def test_max_bins_64(oracle):
+    """GF_MAX_BINS = 64 energy bins in the flux average (the reference default is 20)."""
+    ps = Cf.texture_paramset(3)
+    edges = np.logspace(np.log10(6e4), np.log10(1e7), 65)
+    src = np.array([0.2, 0.8, 0.0])
+    om = oracle.make_model(ps, "BSM_GAUSS", texture="OUT", dimension=3, binning=edges, source_ratio=src,
+                           bestfit_fr=(1 / 3,) * 3, smearing=0.05)
+    desc = compile_model(ps, "BSM_GAUSS", texture=Texture.OUT, dimension=3, binning=edges, source_ratio=src,
+                         bestfit_fr=(1 / 3,) * 3, smearing=0.05)
+    assert desc.nbins == 64
+    rng = np.random.default_rng(64)
+    th = uniform_theta(ps, 1500, rng, seeds=True)
+    th[:, 6] = rng.uniform(-32, -24, len(th))
+    ref, ref_fr, ref_st = oracle.lnprob_batch(om, th, want_fr=True, want_status=True)
+    with Model(desc) as m:
+        lp, fr, st = m.lnprob(th, want_fr=True)
+    good = (ref_st == 0) & (st == 0)
+    assert good.mean() > 0.95
+    assert np.abs(fr[good] - ref_fr[good]).max() <= ABS_FR
+    fin = good & np.isfinite(ref)
+    assert rel_err(lp[fin], ref[fin]) <= REL
+    with pytest.raises(ValueError):
+        compile_model(ps, "BSM_GAUSS", texture=Texture.OUT, dimension=3, binning=np.logspace(4, 7, 67),
+                      bestfit_fr=(1 / 3,) * 3, smearing=0.05)
