@@ -90,10 +90,19 @@ def cpu_baseline(ps, bf, theta, sample):
     t0 = time.perf_counter()
     ref = O.lnprob_batch(om, ths, threads=cores)
     tm = time.perf_counter() - t0
+    # the Python reference itself never travels to the GPU box; its rate was measured in the build
+    # container when the golden vectors were generated (tests/golden/golden_meta.json, 1 core)
+    ref_rate = None
+    try:
+        meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_meta.json")))
+        ref_rate = 1e6 / meta["timings"]["notebook_ln_prob_us"]
+    except Exception:
+        pass
     return {"value": n / tm, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d evaluations of the bench theta batch, oracle/golem_oracle.c (long double), %d threads; "
                       "single-thread rate %.3g evals/s on %d evaluations" % (n, cores, rate1, len(th1)),
-            "single_thread_value": rate1}, ref
+            "single_thread_value": rate1,
+            "reference_python_evals_per_s_1core_build_container": ref_rate}, ref
 
 
 def _claim_stdout():
