@@ -406,3 +406,38 @@ def test_max_bins_64(oracle):
     with pytest.raises(ValueError):
         compile_model(ps, "BSM_GAUSS", texture=Texture.OUT, dimension=3, binning=np.logspace(4, 7, 67),
                       bestfit_fr=(1 / 3,) * 3, smearing=0.05)
+
+
+# ---------------------------------------------------------------- every specialisation of the fast SM kernel
+@pytest.mark.parametrize("case", ["permuted6", "fixed_source4", "odd7", "wide12"])
+def test_fast_kernel_specialisations(oracle, case):
+    """k_lnprob_sm_fast is instantiated per (ndim, sampled/canonical, fr): cover the non-canonical column
+    order (named re-reads from LDS), a fixed source (scalar constants), an odd row length (half-filled last
+    16-B vector of the tile) and the 12-column tile, each on a ragged n that also exercises the tail kernel."""
+    asimov, nb = Cf.notebook_paramsets((0.5373597586219514, 0.5006819093249053))
+    nbl = list(nb)
+    lg = Cf.PriorsCateg.LIMITEDGAUSS
+    kw = dict(bestfit_fr=(0.55, 0.18, 0.27), smearing=0.02)
+    if case == "permuted6":
+        ps = ParamSet([nbl[4], nbl[0], nbl[5], nbl[3], nbl[1], nbl[2]])
+    elif case == "fixed_source4":
+        ps = ParamSet(nbl[:4])
+        kw["source_ratio"] = (0.2, 0.7, 0.1)
+    elif case == "odd7":
+        ps = ParamSet(nbl + [Param(name="extra", value=1.0, ranges=[0., 2.], std=0.25, prior=lg, tag=ParamTag.NUISANCE)])
+    else:
+        ps = ParamSet(nbl + [Param(name="n%d" % i, value=1.0, ranges=[0., 2.], std=0.3, prior=lg if i % 2 else None,
+                                   tag=ParamTag.NUISANCE) for i in range(6)])
+    om = oracle.make_model(ps, "SM_GAUSS", **kw)
+    rng = np.random.default_rng(len(ps))
+    n = 64 * 37 + 29
+    th = np.vstack([uniform_theta(ps, n - 500, rng, seeds=True), uniform_theta(ps, 500, rng, seeds=False)])
+    ref, ref_fr = oracle.lnprob_batch(om, th, want_fr=True)
+    with Model(compile_model(ps, "SM_GAUSS", **kw)) as m:
+        lp, fr, st = m.lnprob(th, want_fr=True)
+        lp_nofr = m.lnprob(th, want_status=False)
+    assert np.array_equal(np.isinf(lp), np.isinf(ref))
+    assert rel_err(lp, ref) <= REL
+    ok = np.isfinite(ref)
+    assert np.abs(fr[ok] - ref_fr[ok]).max() <= ABS_FR
+    assert np.array_equal(lp, lp_nofr, equal_nan=True)
