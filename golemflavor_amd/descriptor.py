@@ -44,7 +44,7 @@ def log_gauss_mass(a, b):
 
 def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=-320.0,
                   source_ratio=(1.0, 2.0, 0.0), texture=Texture.NONE, dimension=3, binning=None,
-                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=0.0, mm_fixed=(0.0, 0.0, 0.0, 0.0)):
+                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=(0.0, 0.0, 0.0, 0.0)):
     """Flatten a posterior definition into a `GfModelDesc`.
 
     llh_paramset : ParamSet whose order is the column order of theta.
@@ -114,7 +114,7 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
 
     scale_idx = [i for i, p in enumerate(params) if p.tag is ParamTag.SCALE]
     d.idx_scale = scale_idx[0] if scale_idx else -1
-    d.scale_fixed = float(scale_fixed)
+    d.scale_fixed = float(scale_fixed) if scale_fixed is not None else 0.0
     mm_idx = [i for i, p in enumerate(params) if p.tag is ParamTag.MMANGLES]
     for k in range(4):
         d.idx_mm[k] = mm_idx[k] if len(mm_idx) == 4 else -1
@@ -135,8 +135,8 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
             raise ValueError("BSM mode needs the energy bin edges")
         if d.texture == Texture.NONE.value and len(mm_idx) != 4:
             raise ValueError("texture NONE needs four MMANGLES params (fr.py:378)")
-        if d.idx_scale < 0:
-            raise ValueError("BSM mode needs a SCALE-tagged param (logLam)")
+        if d.idx_scale < 0 and scale_fixed is None:
+            raise ValueError("BSM mode needs a SCALE-tagged param (logLam) or an explicit scale_fixed")
         edges = np.asarray(binning, dtype=np.float64)
         if edges.ndim != 1 or not 2 <= edges.size <= _lib.GF_MAX_BINS + 1:
             raise ValueError("binning must hold 2..%d edges" % (_lib.GF_MAX_BINS + 1))

@@ -84,3 +84,16 @@ def test_rccl_binding_world_size_1():
         assert np.array_equal(chains[1], x + 1)
     b.barrier()
     b.close()
+
+
+def test_grid_scans_c4_c5_smoke(capsys):
+    """BASELINE configs C4 / C5 end to end on one rank, reduced sizes: sharded grid -> device sampler ->
+    (C4) flux-averaged post-processing -> gathered chains."""
+    import json
+    from golemflavor_amd import scan
+    scan.main(["--config", "C4", "--points", "3", "--nwalkers", "32", "--burnin", "10", "--nsteps", "15"])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["chains_shape"] == [3, 32 * 15, 9] and out["finite_fraction"] > 0.9
+    scan.main(["--config", "C5", "--points", "2", "--nwalkers", "32", "--burnin", "5", "--nsteps", "10"])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0
