@@ -37,6 +37,9 @@ using namespace gfdev;
 // induction variables and bounds checks out of the register budget.
 // theta is read once and lnprob written once per launch: nontemporal accesses keep the stream from
 // displacing useful lines (measured +4..8 % on the full kernel, +15 % on a bare stream of this traffic mix).
+// Compile-time A/B switches (tools/build_variants.sh; results in profiles/r01/ab_*): GF_NO_NT,
+// GF_PREFETCH_DEPTH, GF_SM_WAVES_PER_EU, GF_BLOCKS_PER_CU, and the diagnostic builds GF_NO_LOADS (compute
+// only) / GF_STRIP_COMPUTE (memory only).  The defaults below are the measured best.
 #ifndef GF_NO_NT
 #define GF_LOAD_THETA(p) __builtin_nontemporal_load(p)
 #define GF_STORE_OUT(p, v) __builtin_nontemporal_store(v, p)
@@ -85,9 +88,10 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
         for (int j = 0; j < VPL; ++j)
             if (EVEN || j * GF_WAVE + lane < NV) pre[p][j] = GF_LOAD_THETA(src + j * GF_WAVE + lane);
     }
-    // The lnprob store of tile t is issued at the top of iteration t+1, AFTER the wait for tile t+1's
-    // loads: with loads and a store pending together the compiler must wait vmcnt(0) (mixed VMEM event
-    // types), which would put the store's write-acknowledge latency on every iteration's critical path.
+    // The lnprob store of tile t is issued at the top of iteration t+1, after the wait for tile t+1's
+    // loads: with loads and a store pending together the compiler waits vmcnt(0) (mixed VMEM event types),
+    // so a store issued at the end of an iteration would put its write-acknowledge on the next wait.
+    // (Measured neutral on MI355X at 4 waves/SIMD -- other waves cover it -- kept because it is free.)
     double val_prev = 0.0;
     int64_t i_prev = -1;
     for (; t < nfull; t += stride) {
