@@ -264,12 +264,13 @@ def test_bsm_golden_lnprob_12dim(golden, oracle):
         assert np.abs(fr[has] - exact[has]).max() <= 1e-11
 
 
-@pytest.mark.parametrize("dim,tex", [(3, Texture.OET), (6, Texture.OUT), (6, Texture.OEU), (4, Texture.OET)])
+@pytest.mark.parametrize("dim,tex", [(3, Texture.OET), (6, Texture.OUT), (6, Texture.OEU), (4, Texture.OET),
+                                     (5, Texture.OEU), (7, Texture.OUT), (8, Texture.OET)])
 def test_bsm_random_vs_oracle(oracle, dim, tex):
-    """Seeded random walkers of the C4 (7-dim) posterior vs the oracle.  The oracle is an 80-bit
-    evaluation of the reference's closed form and carries its noise (up to ~3e-9 in the top ~4 decades of
-    the scale range, where the reference starts failing its own unitarity assert); outside that corner the
-    bar is the plain 1e-10."""
+    """Seeded random walkers of the C4 (7-dim) posterior vs the oracle, every operator dimension the
+    reference scans (fr.py:45-52).  The oracle is an 80-bit evaluation of the reference's closed form and
+    carries its noise near the top of each scale range, where the reference starts failing its own
+    unitarity assert; away from there the bar is the plain 1e-10."""
     ps = Cf.texture_paramset(dim)
     lo, hi = Cf.SCALE_BOUNDARIES[dim]
     rng = np.random.default_rng(1000 + dim + tex.value)
@@ -282,12 +283,18 @@ def test_bsm_random_vs_oracle(oracle, dim, tex):
         lp, fr, st = m.lnprob(th, want_fr=True)
         lp_nochk = m.lnprob(th, want_status=False)
     good = (ref_st == 0) & (st == 0)
-    calm = good & (th[:, 6] < hi - 5)
-    assert calm.sum() > 2000
-    assert np.abs(fr[calm] - ref_fr[calm]).max() <= ABS_FR
-    fin = calm & np.isfinite(ref)
+    # The oracle's eigenvector matrix is only unitary to r80 (the number the reference compares with 1e-7,
+    # fr.py:493-494); its composition carries an error of that order.  Bar: 1e-10 plus that defect, per
+    # walker.  (Checked against 60-digit arithmetic: where the two differ by more than 1e-10 it is the
+    # 80-bit closed form that is off, e.g. dim 7, logLam = -38: oracle 1e-8 from exact, kernel 4e-15.)
+    r80 = oracle.unitarity_residual_batch(om, th)
+    tol = ABS_FR + 10.0 * r80            # measured worst ratio error / defect: 7 (tools/diag_bsm_r80.py)
+    assert np.all(np.abs(fr[good] - ref_fr[good]).max(axis=1) <= tol[good])
+    clean = good & (r80 < 1e-13)
+    assert clean.sum() > 2000
+    assert np.abs(fr[clean] - ref_fr[clean]).max() <= ABS_FR
+    fin = clean & np.isfinite(ref)
     assert rel_err(lp[fin], ref[fin]) <= REL
-    assert np.abs(fr[good] - ref_fr[good]).max() <= 1e-7       # the reference's own unitarity tolerance
     assert np.abs(fr[st != 1].sum(axis=1) - 1).max() < 1e-13
     # status agreement: the emulated unitarity verdict matches the oracle's on nearly every walker
     agree = np.mean((st == _lib.GF_ST_NON_UNITARY) == (ref_st == 2))
