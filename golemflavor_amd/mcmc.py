@@ -243,6 +243,19 @@ class DeviceEnsembleSampler:
         pos, lnp = self.state
         return pos, lnp, None
 
+    def run_async(self, pos0, N, thin=1, storechain=True):
+        """Enqueue N steps on the model's stream and return immediately; pair with `wait()`.  Samplers of
+        different models live on different streams, so several small ensembles overlap on the GPU."""
+        if pos0 is not None:
+            self._set_state(pos0)
+        if not self._have_state:
+            raise ValueError("no starting position")
+        self._lib.check(self._L.gf_sampler_run(self._h, int(N), int(thin), 1 if storechain else 0), "gf_sampler_run")
+
+    def wait(self):
+        self._lib.check(self._L.gf_sampler_sync(self._h), "gf_sampler_sync")
+        self._check_flags()
+
     def sample(self, p0, iterations=1, thin=1, storechain=True, chunk=None):
         """Generator with emcee-2's shape: yields (pos, lnprob, state) after every `chunk` steps
         (default: ~100 yields per call) so progress bars keep working without a sync per step."""
@@ -358,13 +371,21 @@ class DeviceEnsembleSampler:
             pass
 
 
-def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident=False, seed=0):
+def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident=None, seed=None):
     """Run the MCMC: burn-in, reset, production; returns samples reshaped to (-1, ndim).
 
-    Same signature, prints and return as golemflavor/mcmc.py:27-53.  `device_resident=True` (needs a
-    golemflavor_amd LnProb) runs the whole chain on the GPU (DeviceEnsembleSampler) instead of one
-    launch per half-ensemble from the host."""
+    Same signature, prints and return as golemflavor/mcmc.py:27-53.  When `ln_prob` is a
+    golemflavor_amd LnProb the whole chain runs on the GPU (DeviceEnsembleSampler: proposal, lnprob
+    and accept in one launch per half-ensemble, walkers resident in HBM); `device_resident=False`
+    forces the host-driven sampler (one launch + PCIe round trip per half-ensemble), which is also
+    what any plain Python callable gets.  `seed` keys the device sampler's Philox stream (default:
+    drawn from numpy's global RNG, so `np.random.seed(args.seed)` makes runs reproducible as in the
+    reference's scripts)."""
+    if device_resident is None:
+        device_resident = hasattr(getattr(ln_prob, "model", None), "_h")
     if device_resident:
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
         sampler = DeviceEnsembleSampler(nwalkers, ndim, ln_prob, seed=seed)
     else:
         sampler = EnsembleSampler(nwalkers, ndim, ln_prob, threads=threads)

@@ -33,29 +33,32 @@ def texture_grid(dimension=6, n_scales=8, n_sources=8):
             for s in np.linspace(lo, hi, n_scales) for x in np.linspace(0, 1, n_sources)]
 
 
-def run_texture_point(point, g, *, dimension, texture, nwalkers, burnin, nsteps, device, seed=25):
+class _TexturePoint:
     """One grid point of scripts/mc_texture.py: flat-likelihood chain over the mixing/mass priors
     (mc_texture.py:148-170), then flux_averaged_BSMu of every sample (mc_texture.py:216-221) at this
-    point's scale and source ratio.  Returns (nwalkers*nsteps, 3 + 6): fr columns then the sample."""
-    scale, source = point
-    ps6 = Cf.ParamSet(list(Cf.texture_paramset(dimension))[:6])            # scale fixed per grid point
-    prior = llh_utils.prior_ln_prob(ps6, device=device)
-    rng = np.random.default_rng(seed + g)
-    box = np.array(ps6.seeds, dtype=float)
-    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 6))             # mcmc.flat_seed, seeded per point
-    s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, prior, seed=seed + g)
-    s.run_mcmc(p0, burnin, storechain=False)
-    s.reset()
-    s.run_mcmc(None, nsteps)
-    samples = s.flatchain                                                   # (nwalkers*nsteps, 6)
-    s.close()
-    prior.close()
-    desc = compile_model(ps6, "BSM_GAUSS", texture=texture, dimension=dimension, binning=Cf.default_bin_edges(),
-                         source_ratio=source, scale_fixed=scale, bestfit_fr=(1 / 3,) * 3, smearing=0.02)
-    with Model(desc, device=device) as m:
-        frs, st = m.propagate(samples)
-    frs[st != 0] = np.nan                                                   # the reference would have raised there
-    return np.column_stack([frs, samples])
+    point's scale and source ratio.  Result: (nwalkers*nsteps, 3 + 6): fr columns then the sample."""
+
+    def __init__(self, point, g, *, dimension, texture, nwalkers, device, seed=25):
+        self.scale, self.source = point
+        self.dimension, self.texture, self.device = dimension, texture, device
+        self.ps6 = Cf.ParamSet(list(Cf.texture_paramset(dimension))[:6])       # scale fixed per grid point
+        self.prior = llh_utils.prior_ln_prob(self.ps6, device=device)
+        rng = np.random.default_rng(seed + g)
+        box = np.array(self.ps6.seeds, dtype=float)
+        self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 6))        # mcmc.flat_seed, seeded per point
+        self.sampler = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, self.prior, seed=seed + g)
+
+    def collect(self):
+        samples = self.sampler.flatchain                                       # (nwalkers*nsteps, 6)
+        self.sampler.close()
+        self.prior.close()
+        desc = compile_model(self.ps6, "BSM_GAUSS", texture=self.texture, dimension=self.dimension,
+                             binning=Cf.default_bin_edges(), source_ratio=self.source, scale_fixed=self.scale,
+                             bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+        with Model(desc, device=self.device) as m:
+            frs, st = m.propagate(samples)
+        frs[st != 0] = np.nan                                                  # the reference would have raised there
+        return np.column_stack([frs, samples])
 
 
 def sens_grid(n_scales=8, n_sources=8):
@@ -70,27 +73,44 @@ def sens_grid(n_scales=8, n_sources=8):
     return pts
 
 
-def run_sens_point(point, g, *, nwalkers, burnin, nsteps, device, seed=25, smearing=0.02):
+class _SensPoint:
     """One grid point of the 12-dim posterior (scripts/fr.py:62-104 paramset, llh.py:121-130 with the
-    Gaussian substitute): logLam seeded around the point's scale; returns the flat chain (.., 12)."""
-    dim, tex, source, scale = point
-    inj = fr_utils.fr_to_angles((1, 1, 1))
-    asimov, ps = Cf.fr_paramsets(dim, inj)
-    args = argparse.Namespace(source_ratio=np.array(source), dimension=dim, texture=tex, binning=Cf.default_bin_edges())
-    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=smearing, device=device, on_nonunitary="-inf")
-    rng = np.random.default_rng(seed + g)
-    box = np.array(ps.seeds, dtype=float)
-    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 12))
-    lo, hi = Cf.SCALE_BOUNDARIES[dim]
-    p0[:, 11] = np.clip(rng.normal(scale, 0.5, nwalkers), lo, hi)
-    s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 12, f, seed=seed + g)
-    s.run_mcmc(p0, burnin, storechain=False)
-    s.reset()
-    s.run_mcmc(None, nsteps)
-    out = s.flatchain
-    s.close()
-    f.close()
-    return out
+    Gaussian substitute): logLam seeded around the point's scale; result: the flat chain (.., 12)."""
+
+    def __init__(self, point, g, *, nwalkers, device, seed=25, smearing=0.02):
+        dim, tex, source, scale = point
+        inj = fr_utils.fr_to_angles((1, 1, 1))
+        asimov, ps = Cf.fr_paramsets(dim, inj)
+        args = argparse.Namespace(source_ratio=np.array(source), dimension=dim, texture=tex, binning=Cf.default_bin_edges())
+        self.f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=smearing, device=device, on_nonunitary="-inf")
+        rng = np.random.default_rng(seed + g)
+        box = np.array(ps.seeds, dtype=float)
+        self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 12))
+        lo, hi = Cf.SCALE_BOUNDARIES[dim]
+        self.p0[:, 11] = np.clip(rng.normal(scale, 0.5, nwalkers), lo, hi)
+        self.sampler = mcmc_utils.DeviceEnsembleSampler(nwalkers, 12, self.f, seed=seed + g)
+
+    def collect(self):
+        out = self.sampler.flatchain
+        self.sampler.close()
+        self.f.close()
+        return out
+
+
+def run_points(points, indices, make, burnin, nsteps):
+    """All of this rank's grid points advance together: every sampler enqueues its launches on its own
+    stream (run_async) before anybody waits, so small ensembles overlap on the GPU."""
+    jobs = {g: make(points[g], g) for g in indices}
+    for j in jobs.values():
+        j.sampler.run_async(j.p0, burnin, storechain=False)
+    for j in jobs.values():
+        j.sampler.wait()
+        j.sampler.reset()
+    for j in jobs.values():
+        j.sampler.run_async(None, nsteps)
+    for j in jobs.values():
+        j.sampler.wait()
+    return {g: j.collect() for g, j in jobs.items()}
 
 
 def main(argv=None):
@@ -119,15 +139,17 @@ def main(argv=None):
     if a.config == "C4":
         pts = texture_grid(a.dimension)[:a.points]
         nw = a.nwalkers or 2048
-        run = lambda p, g: run_texture_point(p, g, dimension=a.dimension, texture=Texture[a.texture], nwalkers=nw,  # noqa: E731
-                                             burnin=a.burnin, nsteps=a.nsteps, device=device)
+        make = lambda p, g: _TexturePoint(p, g, dimension=a.dimension, texture=Texture[a.texture], nwalkers=nw,  # noqa: E731
+                                          device=device)
         evals_per_point = nw * (a.burnin + a.nsteps) + nw * a.nsteps
     else:
         pts = sens_grid()[:a.points]
         nw = a.nwalkers or 512
-        run = lambda p, g: run_sens_point(p, g, nwalkers=nw, burnin=a.burnin, nsteps=a.nsteps, device=device)  # noqa: E731
+        make = lambda p, g: _SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
         evals_per_point = nw * (a.burnin + a.nsteps)
-    chains = gdist.run_grid(pts, run, backend)
+    mine = gdist.shard(len(pts), backend.rank, backend.world)
+    local = run_points(pts, mine, make, a.burnin, a.nsteps)
+    chains = gdist.gather_chains(local, len(pts), backend)
     dt = time.perf_counter() - t0
     if rank == 0:
         arr = np.stack(chains)

@@ -36,7 +36,8 @@ def test_config1_notebook_chain_through_mcmc(golden, capsys):
     f = llh_utils.notebook_ln_prob(asimov, ps)
     np.random.seed(26)
     p0 = mcmc_utils.flat_seed(ps, nwalkers=100)
-    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1200, threads=1)
+    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1200, threads=1,
+                              device_resident=False)
     out = capsys.readouterr().out
     assert samples.shape == (100 * 1200, 6)
     assert f.ncalls == 2 + 2 * 1600 and f.nevals == 200 + 100 * 1600

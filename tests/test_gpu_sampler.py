@@ -137,7 +137,7 @@ def test_mcmc_driver_device_resident(golden, capsys):
     f = llh_utils.notebook_ln_prob(asimov, ps)
     np.random.seed(26)
     p0 = mcmc_utils.flat_seed(ps, nwalkers=100)
-    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500, device_resident=True, seed=5)
+    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500)   # LnProb -> device-resident
     out = capsys.readouterr().out
     assert samples.shape == (100 * 1500, 6)
     acc = float(out.split("sum of acceptance fraction")[1].split()[0]) / 100
@@ -145,7 +145,7 @@ def test_mcmc_driver_device_resident(golden, capsys):
     assert f.ncalls == 0                                       # no host-driven evaluations at all
     # same posterior as the host-driven sampler
     np.random.seed(26)
-    host = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500)
+    host = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500, device_resident=False)
     capsys.readouterr()
     for d in range(6):
         sd = host[:, d].std()
