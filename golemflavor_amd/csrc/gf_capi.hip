@@ -247,6 +247,12 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
     }
     c.offset = d->offset;
     c.flat_llh = d->flat_llh;
+    {
+        static const double cosc[8] = {2.7117413873509064e-15, -7.641995277350052e-13, 1.605889634387573e-10,
+                                       -2.505210587009456e-08, 2.75573191979119e-06, -0.00019841269841110079,
+                                       0.008333333333332799, -0.16666666666666657};
+        for (int k = 0; k < 8; ++k) c.cosc[k] = cosc[k];
+    }
 
     GfBsm& b = m->hb;
     if (d->mode == GF_MODE_BSM_GAUSS) {

@@ -36,6 +36,9 @@ struct GfCommon {
     double gauss_k;                 // -0.5 * gauss_c0
     double offset;
     double flat_llh;
+    // minimax coefficients of fast_cos_phase, passed through the kernel arguments so that they sit in
+    // scalar registers (literals get materialised in VGPRs and cost a v_mov per Horner step)
+    double cosc[8];
 };
 
 // BSM tables (device memory, read with uniform indices -> scalar loads).

@@ -10,6 +10,12 @@
 #define GF_BLOCK 256
 #define GF_WAVES_PER_BLOCK (GF_BLOCK / GF_WAVE)
 
+#ifdef GF_COS_LITERALS            // A/B switch: polynomial coefficients as literals instead of kernarg SGPRs
+#define GF_COSC(c) nullptr
+#else
+#define GF_COSC(c) (c).cosc
+#endif
+
 namespace gfdev {
 
 constexpr int ST_OK = 0, ST_OUT_OF_PRIOR = 1, ST_NON_UNITARY = 2, ST_NAN = 3;
@@ -98,18 +104,29 @@ static __device__ __attribute__((noinline)) double cos_general(double x) { retur
 // u = |x - pi| - pi/2 in [-pi/2, pi/2] where cos x = sin u, and evaluates one odd minimax polynomial
 // (9 terms, fitted in 50-digit arithmetic: approximation error 3e-19, end-to-end abs error <= 2.8e-16).
 // Any other x takes cos_general.
-__device__ __forceinline__ double fast_cos_phase(double x)
+__device__ __forceinline__ double fast_cos_phase(double x, const double* k = nullptr)
 {
     const double u = fabs(x - 3.141592653589793) - 1.5707963267948966;
     if (!(fabs(u) <= 1.5707963277948966)) return cos_general(x);     // pi/2 + 1e-9; NaN goes here too
     const double z = u * u;
-    double q = fma(z, 2.7117413873509064e-15, -7.641995277350052e-13);
-    q = fma(z, q, 1.605889634387573e-10);
-    q = fma(z, q, -2.505210587009456e-08);
-    q = fma(z, q, 2.75573191979119e-06);
-    q = fma(z, q, -0.00019841269841110079);
-    q = fma(z, q, 0.008333333333332799);
-    q = fma(z, q, -0.16666666666666657);
+    double q;
+    if (k) {                               // coefficients from kernel-argument SGPRs (GfCommon::cosc)
+        q = fma(z, k[0], k[1]);
+        q = fma(z, q, k[2]);
+        q = fma(z, q, k[3]);
+        q = fma(z, q, k[4]);
+        q = fma(z, q, k[5]);
+        q = fma(z, q, k[6]);
+        q = fma(z, q, k[7]);
+    } else {
+        q = fma(z, 2.7117413873509064e-15, -7.641995277350052e-13);
+        q = fma(z, q, 1.605889634387573e-10);
+        q = fma(z, q, -2.505210587009456e-08);
+        q = fma(z, q, 2.75573191979119e-06);
+        q = fma(z, q, -0.00019841269841110079);
+        q = fma(z, q, 0.008333333333332799);
+        q = fma(z, q, -0.16666666666666657);
+    }
     return fma(u * z, q, u);
 }
 
@@ -235,7 +252,8 @@ __device__ __forceinline__ bool lnprior(const GfCommon& c, const double* row, do
 //   |Ut1|^2 = s12^2 s23^2 + c12^2 c23^2 s13^2 - 2 J cos d,   |Ut2|^2 = c12^2 s23^2 + s12^2 c23^2 s13^2 + 2 J cos d,
 // J = s12 c12 s23 c23 s13 = sqrt(s12^2 c12^2 s23^2 c23^2 s13^2)   (all five factors are >= 0: the
 // reference takes the angles in [0, pi/2] via asin/acos of a square root, fr.py:145-147).
-__device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23_2, double dcp, double p[3][3])
+__device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23_2, double dcp, double p[3][3],
+                                          const double* cosc = nullptr)
 {
     const double c13_2 = fast_sqrt(c13_4);
     const double s13_2 = 1.0 - c13_2;
@@ -243,7 +261,7 @@ __device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23
     const double c23_2 = 1.0 - s23_2;
     const double a = s12_2 * c23_2, b = c12_2 * s23_2;
     const double e = c12_2 * c23_2, f = s12_2 * s23_2;
-    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos_phase(dcp);
+    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos_phase(dcp, cosc);
     p[0][0] = c12_2 * c13_2;
     p[0][1] = s12_2 * c13_2;
     p[0][2] = s13_2;
@@ -375,12 +393,12 @@ __device__ __forceinline__ void eval_walker(const GfCommon& c, const double* cta
         double f[3];
         if (SAMPLED == 2) {                              // canonical columns 0..5: reuse the row registers
             double p[3][3], src[3];
-            pmns_abs2(row[0], row[1], row[2], row[3], p);
+            pmns_abs2(row[0], row[1], row[2], row[3], p, GF_COSC(c));
             angles_to_fr(row[4], row[5], src);
             propagate(p, src, (src[0] + src[1]) + src[2], f);
         } else if (SAMPLED == 1) {
             double p[3][3], src[3];
-            pmns_abs2(row[c.idx_sm[0]], row[c.idx_sm[1]], row[c.idx_sm[2]], row[c.idx_sm[3]], p);
+            pmns_abs2(row[c.idx_sm[0]], row[c.idx_sm[1]], row[c.idx_sm[2]], row[c.idx_sm[3]], p, GF_COSC(c));
             angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
             propagate(p, src, (src[0] + src[1]) + src[2], f);
         } else {
