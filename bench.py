@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--walkers", type=int, default=4096, help="walkers per ensemble (BASELINE config 2)")
     ap.add_argument("--ensembles", type=int, default=4096, help="independent ensembles stacked per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the emcee-driven extra (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="evaluations in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -246,7 +247,7 @@ def main():
             out["rccl_gather_ok"] = gathered_ok
         if rccl_error is not None:
             out["rccl_error"] = rccl_error
-        if world == 1:
+        if world == 1 and not a.no_sampler:
             # emcee-driven figure (not `value`): one 4096-walker ensemble advanced by the device-resident
             # stretch-move sampler, 2 launches per step, walkers never leave HBM
             try:
