@@ -128,6 +128,7 @@ def main():
     dist = None
     comm = None
     rccl_error = None
+    hard_exit = False          # a stuck RCCL bootstrap thread would block interpreter shutdown
     L = _lib.lib()
     ps, bf, desc = notebook_descriptor()
     if world > 1:
@@ -139,6 +140,20 @@ def main():
         # region has no collective, so an RCCL problem must not cost the measurement: fall back to gloo
         # for the descriptor broadcast and report the failure in the JSON line.
         rccl_error = None
+        box = {}
+
+        def _rccl_setup():
+            try:
+                h = C.c_void_p()
+                _lib.check(L.gf_comm_create(idb, rank, world, local_rank, C.byref(h)), "gf_comm_create")
+                box["comm"] = h
+                # fixed physics constants: rank 0's packed descriptor is the one everybody uses
+                raw = (C.c_uint8 * C.sizeof(desc)).from_buffer(desc)
+                _lib.check(L.gf_comm_broadcast(h, raw, C.sizeof(desc), 0), "gf_comm_broadcast")
+                box["ok"] = True
+            except Exception as exc:       # noqa: BLE001
+                box["err"] = "%s: %s" % (type(exc).__name__, exc)
+
         try:
             ids = [None]
             if rank == 0:
@@ -147,12 +162,18 @@ def main():
                 ids = [bytes(buf)]
             dist.broadcast_object_list(ids, src=0)
             idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(ids[0])
-            h = C.c_void_p()
-            _lib.check(L.gf_comm_create(idb, rank, world, local_rank, C.byref(h)), "gf_comm_create")
-            comm = h
-            # fixed physics constants: rank 0's packed descriptor is the one everybody uses
-            raw = (C.c_uint8 * C.sizeof(desc)).from_buffer(desc)
-            _lib.check(L.gf_comm_broadcast(comm, raw, C.sizeof(desc), 0), "gf_comm_broadcast")
+            # a communicator that cannot bootstrap must not hang the measurement: bounded wait
+            import threading
+            th = threading.Thread(target=_rccl_setup, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "120")))
+            if th.is_alive():
+                rccl_error = "timeout: RCCL communicator setup did not finish"
+                hard_exit = True
+            elif "err" in box:
+                rccl_error = box["err"]
+            else:
+                comm = box["comm"]
         except Exception as exc:           # noqa: BLE001
             rccl_error = "%s: %s" % (type(exc).__name__, exc)
             comm = None
@@ -282,6 +303,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if hard_exit:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
