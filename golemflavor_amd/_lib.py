@@ -82,6 +82,7 @@ SIGNATURES = {
     "gf_event_record": (C.c_int, [_vp, _vp]),
     "gf_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "gf_sampler_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.POINTER(_vp)]),
+    "gf_sampler_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_uint64, C.c_double, C.POINTER(_vp)]),
     "gf_sampler_destroy": (None, [_vp]),
     "gf_sampler_set_state": (C.c_int, [_vp, _dp]),
     "gf_sampler_run": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "gf_sampler_get_state": (C.c_int, [_vp, _dp, _dp]),
     "gf_sampler_get_chain": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gf_sampler_postprocess": (C.c_int, [_vp, _dp, _ip, C.c_int, C.POINTER(C.c_uint64)]),
+    "gf_sampler_postprocess_with": (C.c_int, [_vp, C.POINTER(_vp), _dp, _ip, C.c_int, C.POINTER(C.c_uint64)]),
     "gf_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "gf_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gf_comm_destroy": (None, [_vp]),

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "../../include/golemflavor_hip.h"
 #include "gf_consts.h"
@@ -62,9 +64,11 @@ bool finite_all(const double* p, int n)
 struct gf_model {
     GfCommon c;
     GfBsm hb;
+    void* d_block = nullptr;     // the model's constant block (from the per-device pool): d_ptab | d_bsm
     GfBsm* d_bsm = nullptr;
     double* d_ptab = nullptr;    // [GF_MAX_DIM][4] = {lo, hi, loc, 1/sigma}: the kernels' LDS constant table
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // created on first use (ensure_stream)
+    std::mutex mu;
     int device = 0;
     int cus = 256;
     // staging for the host-buffer entry points (grown on demand, reused across calls)
@@ -77,6 +81,87 @@ struct gf_model {
 };
 
 namespace {
+
+// Per-device cache of what a model needs from the runtime: the device's identity, a non-blocking stream and
+// one small block of device memory for its constant tables.  A grid scan creates and destroys hundreds of
+// models (one per grid point); hipStreamCreate / hipMalloc / hipFree / hipGetDeviceProperties cost ~1 ms each
+// and hipFree synchronises the device, so destroyed models hand their stream and block back to this pool.
+constexpr int POOL_MAX_DEVICES = 64;
+constexpr size_t POOL_MAX_ITEMS = 1024;
+constexpr size_t CONST_PTAB_BYTES = sizeof(double) * GF_MAX_DIM * 4;
+constexpr size_t CONST_BSM_OFFSET = (CONST_PTAB_BYTES + 255) / 256 * 256;
+constexpr size_t CONST_BLOCK_BYTES = CONST_BSM_OFFSET + sizeof(GfBsm);
+
+struct DevicePool {
+    int state = 0;                 // 0 unknown, 1 gfx950, -1 something else
+    int cus = 256;
+    std::vector<hipStream_t> streams;
+    std::vector<void*> blocks;
+};
+std::mutex g_pool_mu;
+DevicePool g_pool[POOL_MAX_DEVICES];
+
+// returns GF_OK and fills cus when `device` is a gfx950
+int pool_device(int device, int* cus)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count || device >= POOL_MAX_DEVICES) {
+        (void)hipGetLastError();
+        std::snprintf(g_err, sizeof(g_err), "no HIP device %d (found %d)", device, count);
+        return GF_ERR_NO_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    DevicePool& dp = g_pool[device];
+    if (dp.state == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); dp.state = -1; }
+        else {
+            dp.state = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+            dp.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+    }
+    if (dp.state != 1) {
+        std::snprintf(g_err, sizeof(g_err), "device %d is not gfx950", device);
+        return GF_ERR_NO_DEVICE;
+    }
+    *cus = dp.cus;
+    return GF_OK;
+}
+
+hipError_t pool_stream(int device, hipStream_t* stream)
+{
+    *stream = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        if (!dp.streams.empty()) { *stream = dp.streams.back(); dp.streams.pop_back(); }
+    }
+    return *stream ? hipSuccess : hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+}
+
+hipError_t pool_block(int device, void** block)
+{
+    *block = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        if (!dp.blocks.empty()) { *block = dp.blocks.back(); dp.blocks.pop_back(); }
+    }
+    return *block ? hipSuccess : hipMalloc(block, CONST_BLOCK_BYTES);
+}
+
+// the stream must be idle (the caller synchronised it)
+void pool_release(int device, hipStream_t stream, void* block)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        if (stream && dp.streams.size() < POOL_MAX_ITEMS) { dp.streams.push_back(stream); stream = nullptr; }
+        if (block && dp.blocks.size() < POOL_MAX_ITEMS) { dp.blocks.push_back(block); block = nullptr; }
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    if (block) (void)hipFree(block);
+}
 
 int ensure_staging(gf_model* m, int64_t n)
 {
@@ -108,30 +193,47 @@ int check_dev_ptr(const void* p, size_t align)
     return GF_OK;
 }
 
-int launch_lnprob(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,
+int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,
                   int32_t* d_status)
 {
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
     else
-        e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
     return GF_OK;
 }
 
-int launch_propagate(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_fr, int32_t* d_status)
+int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, double* d_fr, int32_t* d_status)
 {
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
     else
-        e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, m->stream);
+        e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");
     return GF_OK;
 }
+
+// A model's stream is created (or taken from the pool) the first time one of its entry points needs it:
+// creating a HIP stream costs milliseconds (tools/rtcost.hip: 3.8 ms), and the models of a stacked grid
+// sampler only lend their constants -- their launches go to the sampler's stream.
+int ensure_stream(gf_model* m)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->stream) return GF_OK;
+    hipError_t e = pool_stream(m->device, &m->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    return GF_OK;
+}
+#define GF_STREAM(m)                      \
+    do {                                  \
+        int rs_ = ensure_stream(m);       \
+        if (rs_ != GF_OK) return rs_;     \
+    } while (0)
 
 }  // namespace
 
@@ -292,34 +394,25 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         }
     }
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
-        (void)hipGetLastError();
-        delete m;
-        std::snprintf(g_err, sizeof(g_err), "no HIP device %d (found %d)", device, ndev);
-        return GF_ERR_NO_DEVICE;
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        delete m;
-        std::snprintf(g_err, sizeof(g_err), "device %d is not gfx950", device);
-        return GF_ERR_NO_DEVICE;
-    }
+    int cus = 256;
+    const int drc = pool_device(device, &cus);
+    if (drc != GF_OK) { delete m; return drc; }
     m->device = device;
-    m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    m->cus = cus;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = pool_block(device, &m->d_block);
     if (e == hipSuccess) {
-        double tab[GF_MAX_DIM * 4];
+        // one upload: prior table, then (BSM) the bin / texture tables, into the model's constant block
+        alignas(16) unsigned char img[CONST_BLOCK_BYTES];
+        double* tab = reinterpret_cast<double*>(img);
         for (int i = 0; i < GF_MAX_DIM; ++i) {
             tab[4 * i] = c.lo[i]; tab[4 * i + 1] = c.hi[i]; tab[4 * i + 2] = c.loc[i]; tab[4 * i + 3] = c.inv_sigma[i];
         }
-        e = hipMalloc((void**)&m->d_ptab, sizeof(tab));
-        if (e == hipSuccess) e = hipMemcpy(m->d_ptab, tab, sizeof(tab), hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && d->mode == GF_MODE_BSM_GAUSS) {
-        e = hipMalloc((void**)&m->d_bsm, sizeof(GfBsm));
-        if (e == hipSuccess) e = hipMemcpy(m->d_bsm, &m->hb, sizeof(GfBsm), hipMemcpyHostToDevice);
+        const bool bsm = d->mode == GF_MODE_BSM_GAUSS;
+        if (bsm) std::memcpy(img + CONST_BSM_OFFSET, &m->hb, sizeof(GfBsm));
+        e = hipMemcpy(m->d_block, img, bsm ? CONST_BLOCK_BYTES : CONST_PTAB_BYTES, hipMemcpyHostToDevice);
+        m->d_ptab = reinterpret_cast<double*>(m->d_block);
+        m->d_bsm = bsm ? reinterpret_cast<GfBsm*>(static_cast<unsigned char*>(m->d_block) + CONST_BSM_OFFSET) : nullptr;
     }
     if (e != hipSuccess) {
         int rc = hip_fail(e, "gf_model_create");
@@ -334,9 +427,8 @@ void gf_model_destroy(gf_model* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    if (m->d_bsm) (void)hipFree(m->d_bsm);
-    if (m->d_ptab) (void)hipFree(m->d_ptab);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    pool_release(m->device, m->stream, m->d_block);
     if (m->d_theta) (void)hipFree(m->d_theta);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_status) (void)hipFree(m->d_status);
@@ -346,12 +438,37 @@ void gf_model_destroy(gf_model* m)
 
 int gf_model_ndim(const gf_model* m) { return m ? m->c.ndim : -1; }
 
-// internal (not in the public header): lets gf_sampler.hip reach the model's constants and stream
+// internal (not in the public header): gf_sampler.hip reaches the model's constants and stream through these
 int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, void** stream, int* device)
 {
     if (!m) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     *c = &m->c; *d_bsm = m->d_bsm; *d_ptab = m->d_ptab; *stream = (void*)m->stream; *device = m->device;
     return GF_OK;
+}
+
+// constants only: does not give the model a stream
+int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus)
+{
+    if (!m) return GF_ERR_INVALID_ARG;
+    *c = &m->c; *d_bsm = m->d_bsm; *d_ptab = m->d_ptab; *device = m->device; *cus = m->cus;
+    return GF_OK;
+}
+
+// the model's kernels on a stream of the caller's (the sampler's)
+int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
+                       double* d_fr, int32_t* d_status)
+{
+    if (!m || n < 0) return GF_ERR_INVALID_ARG;
+    return launch_lnprob(m, (hipStream_t)stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
+}
+
+int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
+                          int32_t* d_status)
+{
+    if (!m || n < 0) return GF_ERR_INVALID_ARG;
+    return launch_propagate(m, (hipStream_t)stream, d_theta, layout, n, d_fr, d_status);
 }
 
 // ---- host-buffer entry points ------------------------------------------------------------
@@ -361,6 +478,7 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     if (!m || n < 0 || (n > 0 && (!theta || (with_llh && !lnprob) || (!with_llh && !fr)))) return GF_ERR_INVALID_ARG;
     if (n == 0) return GF_OK;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     int rc = ensure_staging(m, n);
     if (rc != GF_OK) return rc;
     const size_t nd = (size_t)m->c.ndim;
@@ -373,9 +491,9 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     double* d_ln = m->d_out;
     double* d_fr = m->d_out + m->cap;
     if (with_llh)
-        rc = launch_lnprob(m, m->d_theta, GF_LAYOUT_AOS, n, d_ln, fr ? d_fr : nullptr, status ? m->d_status : nullptr);
+        rc = launch_lnprob(m, m->stream, m->d_theta, GF_LAYOUT_AOS, n, d_ln, fr ? d_fr : nullptr, status ? m->d_status : nullptr);
     else
-        rc = launch_propagate(m, m->d_theta, GF_LAYOUT_AOS, n, d_fr, status ? m->d_status : nullptr);
+        rc = launch_propagate(m, m->stream, m->d_theta, GF_LAYOUT_AOS, n, d_fr, status ? m->d_status : nullptr);
     if (rc != GF_OK) return rc;
     if (with_llh) GF_HIP(hipMemcpyAsync(h_out, d_ln, sizeof(double) * n, hipMemcpyDeviceToHost, m->stream));
     if (fr) GF_HIP(hipMemcpyAsync(h_fr, d_fr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, m->stream));
@@ -402,6 +520,7 @@ int gf_haar_draw(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, doub
     if (!m || n < 0 || (n > 0 && !fr)) return GF_ERR_INVALID_ARG;
     if (n == 0) return GF_OK;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     double *d_fr = nullptr, *d_ang = nullptr;
     GF_HIP(hipMalloc((void**)&d_fr, sizeof(double) * 3 * n));
     if (angles) {
@@ -435,7 +554,7 @@ int gf_device_free(gf_model* m, void* dptr)
     if (!m) return GF_ERR_INVALID_ARG;
     if (!dptr) return GF_OK;
     GF_HIP(hipSetDevice(m->device));
-    GF_HIP(hipStreamSynchronize(m->stream));
+    if (m->stream) GF_HIP(hipStreamSynchronize(m->stream));
     GF_HIP(hipFree(dptr));
     return GF_OK;
 }
@@ -444,6 +563,7 @@ int gf_memcpy_h2d(gf_model* m, void* dst_dev, const void* src_host, size_t bytes
 {
     if (!m || !dst_dev || !src_host) return GF_ERR_INVALID_ARG;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     GF_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, m->stream));
     GF_HIP(hipStreamSynchronize(m->stream));
     return GF_OK;
@@ -453,6 +573,7 @@ int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes
 {
     if (!m || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
     GF_HIP(hipStreamSynchronize(m->stream));
     return GF_OK;
@@ -467,7 +588,8 @@ int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64
     if (rc == GF_OK) rc = check_dev_ptr(d_lnprob, 8);
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
-    return launch_lnprob(m, d_theta, layout, n, d_lnprob, d_fr, d_status);
+    GF_STREAM(m);
+    return launch_lnprob(m, m->stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
 }
 
 int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_fr,
@@ -479,7 +601,8 @@ int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, in
     if (rc == GF_OK) rc = check_dev_ptr(d_fr, 8);
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
-    return launch_propagate(m, d_theta, layout, n, d_fr, d_status);
+    GF_STREAM(m);
+    return launch_propagate(m, m->stream, d_theta, layout, n, d_fr, d_status);
 }
 
 int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, double* d_angles, double* d_fr)
@@ -490,6 +613,7 @@ int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t 
     if (rc == GF_OK && d_angles) rc = check_dev_ptr(d_angles, 32);
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     hipError_t e = gf_launch_haar(m->c, seed, first_draw, n, d_angles, d_fr, m->cus, m->stream);
     if (e != hipSuccess) return hip_fail(e, "haar launch");
     return GF_OK;
@@ -504,6 +628,7 @@ int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int n
     if (rc == GF_OK) rc = check_dev_ptr(d_counts, 8);
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     hipError_t e = gf_launch_flavor_hist(d_fr, n, nbins, (unsigned long long*)d_counts, m->cus, m->stream);
     if (e != hipSuccess) return hip_fail(e, "histogram launch");
     return GF_OK;
@@ -514,6 +639,7 @@ int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uin
 {
     if (!m || n < 0 || (n > 0 && !fr) || !counts || nbins < 1 || nbins > 1024) return GF_ERR_INVALID_ARG;
     GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     const size_t nbin3 = (size_t)nbins * nbins * nbins;
     double* d_fr = nullptr;
     uint64_t* d_c = nullptr;
@@ -535,7 +661,7 @@ int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uin
 int gf_model_sync(gf_model* m)
 {
     if (!m) return GF_ERR_INVALID_ARG;
-    GF_HIP(hipStreamSynchronize(m->stream));
+    if (m->stream) GF_HIP(hipStreamSynchronize(m->stream));     // no stream yet: nothing was ever enqueued
     return GF_OK;
 }
 
@@ -558,6 +684,8 @@ int gf_event_destroy(void* ev)
 int gf_event_record(gf_model* m, void* ev)
 {
     if (!m || !ev) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
     GF_HIP(hipEventRecord((hipEvent_t)ev, m->stream));
     return GF_OK;
 }

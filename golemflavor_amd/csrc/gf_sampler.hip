@@ -71,6 +71,10 @@ struct StretchArgs {
     int32_t nchains, nwalkers, half;
     int32_t step_offset;    // step index relative to the device-side base counters
     double a;
+    // one model per chain (gf_sampler_create_multi): chain ch evaluates commons[ch] / tbs[ch] / ptabs[ch]
+    const GfCommon* commons;
+    const GfBsm* const* tbs;
+    const double* const* ptabs;
 };
 
 __global__ void k_tick(StepState* st, int nsteps)
@@ -103,9 +107,11 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
     return val;
 }
 
+// One half-ensemble update for the walkers of one block.  `chain` / `k` = this thread's ensemble and its
+// index in the active half (`valid` false for the padding threads of the last block of a chain).
 template <int NDIM, int MODE>
-__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
-                                                          const double* __restrict__ ptab, const StretchArgs s)
+__device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __restrict__ tb, const double* __restrict__ ptab,
+                                             const StretchArgs& s, const int chain, const int k, const bool valid)
 {
     constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * ND];
@@ -131,11 +137,8 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const
     const bool store_now = s.state->store != 0 && s.chain != nullptr && (run_step % thin) == 0;
     const int64_t store_index = s.state->store_base + (run_step + thin - 1) / thin;   // stored steps before this one
     const int nhalf = s.nwalkers / 2;
-    const int64_t total = (int64_t)s.nchains * nhalf;
-    const int64_t g = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
-    if (g < total) {
-    const int chain = (int)(g / nhalf);
-    const int k = (int)(g - (int64_t)chain * nhalf);
+    const int64_t g = (int64_t)chain * nhalf + k;            // global walker slot: the Philox counter
+    if (valid) {
     const int w = s.half * nhalf + k;                        // this walker, in the active half
     const int cbase = (1 - s.half) * nhalf;                  // complementary half
 
@@ -189,12 +192,44 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const
         if (s.lnp_chain)
             s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
     }
-    }   // g < total
+    }   // valid
+}
+
+// every ensemble samples the same posterior: constants by value (scalar registers), walkers packed densely
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
+                                                          const double* __restrict__ ptab, const StretchArgs s)
+{
+    const int nhalf = s.nwalkers / 2;
+    const int64_t g = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
+    const bool valid = g < (int64_t)s.nchains * nhalf;
+    const int chain = valid ? (int)(g / nhalf) : 0;
+    const int k = valid ? (int)(g - (int64_t)chain * nhalf) : 0;
+    stretch_body<NDIM, MODE>(c, tb, ptab, s, chain, k, valid);
+}
+
+// one posterior per ensemble (grid scans, SURVEY.md 8(e) "all chains of a GPU stacked into one launch"):
+// blockIdx.y = chain, so that a block's constants are block-uniform and come from scalar loads
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch_multi(const StretchArgs s)
+{
+    const int chain = blockIdx.y;
+    const int k = blockIdx.x * GF_BLOCK + threadIdx.x;
+    stretch_body<NDIM, MODE>(s.commons[chain], s.tbs[chain], s.ptabs[chain], s, chain, k, k < s.nwalkers / 2);
 }
 
 template <int NDIM>
 hipError_t launch_stretch_n(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
 {
+    if (a.commons) {
+        const dim3 grid((a.nwalkers / 2 + GF_BLOCK - 1) / GF_BLOCK, a.nchains);
+        switch (c.mode) {
+        case MODE_PRIOR_ONLY: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_PRIOR_ONLY>), grid, dim3(GF_BLOCK), 0, st, a); break;
+        case MODE_SM_GAUSS: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_SM_GAUSS>), grid, dim3(GF_BLOCK), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_BSM_GAUSS>), grid, dim3(GF_BLOCK), 0, st, a); break;
+        }
+        return hipGetLastError();
+    }
     const int64_t total = (int64_t)a.nchains * (a.nwalkers / 2);
     const int grid = (int)((total + GF_BLOCK - 1) / GF_BLOCK);
     switch (c.mode) {
@@ -220,7 +255,11 @@ hipError_t launch_stretch(const GfCommon& c, const GfBsm* tb, const double* ptab
 
 // ---- C ABI ---------------------------------------------------------------------------------------
 struct gf_sampler {
-    gf_model* model = nullptr;
+    gf_model* model = nullptr;          // chain 0's model: its stream carries the sampler's launches
+    gf_model** models = nullptr;        // [nchains] when every chain has its own posterior, else null
+    GfCommon* d_commons = nullptr;      // device copies for k_stretch_multi
+    const GfBsm** d_tbs = nullptr;
+    const double** d_ptabs = nullptr;
     int nchains = 0, nwalkers = 0, ndim = 0;
     uint64_t seed = 0, iteration = 0;
     double a = 2.0;
@@ -243,6 +282,11 @@ struct gf_sampler {
 extern "C" {
 int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, void** stream,
                       int* device);
+int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus);
+int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
+                       double* d_fr, int32_t* d_status);
+int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
+                          int32_t* d_status);
 }
 
 namespace {
@@ -304,7 +348,55 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
+    if (s->d_commons) (void)hipFree(s->d_commons);
+    if (s->d_tbs) (void)hipFree((void*)s->d_tbs);
+    if (s->d_ptabs) (void)hipFree((void*)s->d_ptabs);
+    delete[] s->models;
     delete s;
+}
+
+// One ensemble per model: chain ch samples the posterior of models[ch].  All models must live on the same
+// device and share ndim and mode (one kernel instance); everything else -- priors, fixed values, best fit,
+// smearing, texture, dimension, binning -- may differ.  The models must outlive the sampler.
+int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out)
+{
+    if (!models || !out || nchains < 1) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (int ch = 0; ch < nchains; ++ch)
+        if (!models[ch]) return GF_ERR_INVALID_ARG;
+    const GfCommon* c0; const GfBsm* tb0; const double* ptab0; void* stream0; int device0;
+    if (gf_model_internal(models[0], &c0, &tb0, &ptab0, &stream0, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    GfCommon* hc = new (std::nothrow) GfCommon[nchains];
+    const GfBsm** htb = new (std::nothrow) const GfBsm*[nchains];
+    const double** hpt = new (std::nothrow) const double*[nchains];
+    gf_model** keep = new (std::nothrow) gf_model*[nchains];
+    auto cleanup = [&]() { delete[] hc; delete[] htb; delete[] hpt; };
+    if (!hc || !htb || !hpt || !keep) { cleanup(); delete[] keep; return GF_ERR_ALLOC; }
+    for (int ch = 0; ch < nchains; ++ch) {
+        const GfCommon* c; int device, cus;
+        if (gf_model_constants(models[ch], &c, &htb[ch], &hpt[ch], &device, &cus) != GF_OK || device != device0 ||
+            c->ndim != c0->ndim || c->mode != c0->mode) {
+            std::snprintf(g_serr, sizeof(g_serr), "gf_sampler_create_multi: model %d differs from model 0 in device, ndim or mode", ch);
+            cleanup(); delete[] keep;
+            return GF_ERR_INVALID_ARG;
+        }
+        hc[ch] = *c;
+        keep[ch] = models[ch];
+    }
+    gf_sampler* s = nullptr;
+    int rc = gf_sampler_create(models[0], nchains, nwalkers, seed, a, &s);
+    if (rc != GF_OK) { cleanup(); delete[] keep; return rc; }
+    s->models = keep;
+    hipError_t e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon) * nchains);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_tbs, sizeof(void*) * nchains);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*) * nchains);
+    if (e == hipSuccess) e = hipMemcpy(s->d_commons, hc, sizeof(GfCommon) * nchains, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)s->d_tbs, htb, sizeof(void*) * nchains, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)s->d_ptabs, hpt, sizeof(void*) * nchains, hipMemcpyHostToDevice);
+    cleanup();
+    if (e != hipSuccess) { rc = sfail(e, "gf_sampler_create_multi"); gf_sampler_destroy(s); return rc; }
+    *out = s;
+    return GF_OK;
 }
 
 // p0: [nchains][nwalkers][ndim] host; evaluates lnprob of the start positions on the device.
@@ -316,8 +408,17 @@ int gf_sampler_set_state(gf_sampler* s, const double* pos)
     GFS_HIP(hipSetDevice(device));
     const size_t nw = (size_t)s->nchains * s->nwalkers;
     GFS_HIP(hipMemcpyAsync(s->d_pos, pos, sizeof(double) * nw * s->ndim, hipMemcpyHostToDevice, (hipStream_t)stream));
-    int rc = gf_lnprob_batch_device(s->model, s->d_pos, GF_LAYOUT_AOS, (int64_t)nw, s->d_lnp, nullptr, nullptr);
-    if (rc != GF_OK) return rc;
+    if (!s->models) {
+        int rc = gf_lnprob_batch_device(s->model, s->d_pos, GF_LAYOUT_AOS, (int64_t)nw, s->d_lnp, nullptr, nullptr);
+        if (rc != GF_OK) return rc;
+        GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return GF_OK;
+    }
+    for (int ch = 0; ch < s->nchains; ++ch) {                     // every chain's own posterior, on the sampler's stream
+        int rc = gf_model_lnprob_on(s->models[ch], stream, s->d_pos + (size_t)ch * s->nwalkers * s->ndim, GF_LAYOUT_AOS,
+                                    s->nwalkers, s->d_lnp + (size_t)ch * s->nwalkers, nullptr, nullptr);
+        if (rc != GF_OK) return rc;
+    }
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GF_OK;
 }
@@ -382,6 +483,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     a.chain = store ? s->d_chain : nullptr;
     a.lnp_chain = store ? s->d_lnp_chain : nullptr;
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
+    a.commons = s->d_commons; a.tbs = s->d_tbs; a.ptabs = s->d_ptabs;
     auto steps = [&](int count) -> hipError_t {       // `count` steps relative to the current base, then tick
         for (int i = 0; i < count; ++i) {
             a.step_offset = i;
@@ -486,34 +588,60 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
 //   counts  [nchains][nbins][nbins][nbins]   or NULL (nbins ignored then)
 int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts)
 {
+    return gf_sampler_postprocess_with(s, nullptr, fr, status, nbins, counts);
+}
+
+// Same, but chain ch is propagated with models[ch] instead of the posterior it was sampled from
+// (scripts/mc_texture.py: the chain samples the priors, mc_texture.py:148-170, and every sample is then pushed
+// through flux_averaged_BSMu at the grid point's scale and source, mc_texture.py:216-221).  models == NULL:
+// the sampling models.  Each model must have the sampler's ndim and device.
+int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
+                                uint64_t* counts)
+{
     if (!s || (counts && (nbins < 1 || nbins > 1024))) return GF_ERR_INVALID_ARG;
-    int rc = gf_model_sync(s->model);
-    if (rc != GF_OK || s->nstored == 0) return rc;
+    const GfCommon* c0; const GfBsm* tb; const double* ptab; void* stream; int device0;
+    if (gf_model_internal(s->model, &c0, &tb, &ptab, &stream, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    int cus = 256;
+    for (int ch = 0; ch < s->nchains; ++ch) {
+        gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
+        const GfCommon* c; int device;
+        if (gf_model_constants(mc, &c, &tb, &ptab, &device, &cus) != GF_OK || c->ndim != s->ndim || device != device0)
+            return GF_ERR_INVALID_ARG;
+    }
+    GFS_HIP(hipSetDevice(device0));
+    hipStream_t st = (hipStream_t)stream;
+    GFS_HIP(hipStreamSynchronize(st));
+    if (s->nstored == 0) return GF_OK;
     const int64_t per_chain = s->nstored * s->nwalkers;
     const size_t nbin3 = counts ? (size_t)nbins * nbins * nbins : 0;
     double* d_fr = nullptr;
     int32_t* d_st = nullptr;
     uint64_t* d_c = nullptr;
-    GFS_HIP(hipMalloc((void**)&d_fr, sizeof(double) * 3 * per_chain));
-    hipError_t e = hipSuccess;
-    if (status) e = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain);
+    hipError_t e = hipMalloc((void**)&d_fr, sizeof(double) * 3 * per_chain);
+    if (e == hipSuccess && status) e = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain);
     if (e == hipSuccess && counts) e = hipMalloc((void**)&d_c, sizeof(uint64_t) * nbin3);
+    int rc = GF_OK;
+    // everything in order on the sampler's stream (the one the chain was written on): propagate, histogram,
+    // copies back; the scratch buffers are reused chain after chain, one sync at the end
     for (int ch = 0; ch < s->nchains && e == hipSuccess && rc == GF_OK; ++ch) {
+        gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
         const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
-        rc = gf_propagate_batch_device(s->model, d_theta, GF_LAYOUT_AOS, per_chain, d_fr, d_st);
+        rc = gf_model_propagate_on(mc, stream, d_theta, GF_LAYOUT_AOS, per_chain, d_fr, d_st);
         if (rc != GF_OK) break;
         if (counts) {
-            e = hipMemset(d_c, 0, sizeof(uint64_t) * nbin3);      // null stream: ordered after the sync below
-            if (e == hipSuccess) rc = gf_model_sync(s->model);
-            if (e == hipSuccess && rc == GF_OK) rc = gf_flavor_histogram_device(s->model, d_fr, per_chain, nbins, d_c);
+            e = hipMemsetAsync(d_c, 0, sizeof(uint64_t) * nbin3, st);
+            if (e == hipSuccess) e = gf_launch_flavor_hist(d_fr, per_chain, nbins, (unsigned long long*)d_c, cus, st);
         }
-        if (rc == GF_OK) rc = gf_model_sync(s->model);
-        if (rc != GF_OK) break;
-        if (fr) e = hipMemcpy(fr + (size_t)ch * per_chain * 3, d_fr, sizeof(double) * 3 * per_chain, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && status) e = hipMemcpy(status + (size_t)ch * per_chain, d_st, sizeof(int32_t) * per_chain, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && counts) e = hipMemcpy(counts + (size_t)ch * nbin3, d_c, sizeof(uint64_t) * nbin3, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && fr)
+            e = hipMemcpyAsync(fr + (size_t)ch * per_chain * 3, d_fr, sizeof(double) * 3 * per_chain, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && status)
+            e = hipMemcpyAsync(status + (size_t)ch * per_chain, d_st, sizeof(int32_t) * per_chain, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && counts)
+            e = hipMemcpyAsync(counts + (size_t)ch * nbin3, d_c, sizeof(uint64_t) * nbin3, hipMemcpyDeviceToHost, st);
     }
-    (void)hipFree(d_fr);
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = e2;
+    if (d_fr) (void)hipFree(d_fr);
     if (d_st) (void)hipFree(d_st);
     if (d_c) (void)hipFree(d_c);
     if (rc != GF_OK) return rc;

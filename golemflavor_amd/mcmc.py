@@ -186,7 +186,9 @@ class DeviceEnsembleSampler:
     """The same sampler, resident on the GPU (`gf_sampler_*` in include/golemflavor_hip.h).
 
     Proposal, lnprob and accept/reject of a half-ensemble run in ONE kernel launch and the walkers
-    never leave HBM; `nchains` independent ensembles of one posterior are advanced together.  The
+    never leave HBM; `nchains` independent ensembles of one posterior are advanced together, or -- when
+    `lnpostfn` is a list -- one ensemble per posterior (the grid points of a scan; the posteriors share
+    ndim and mode, everything else may differ).  The
     attribute surface is emcee-2's (`sample`, `run_mcmc`, `reset`, `chain`, `lnprobability`,
     `acceptance_fraction`, `acor`); with `nchains > 1` the arrays gain a leading chain axis.
     Random numbers come from Philox4x32-10 keyed by `seed` (reproducible, independent of launch
@@ -196,11 +198,21 @@ class DeviceEnsembleSampler:
     def __init__(self, nwalkers, dim, lnpostfn, a=2.0, nchains=1, seed=0, threads=1):
         import ctypes as C
         from . import _lib
-        model = getattr(lnpostfn, "model", lnpostfn)
-        if not hasattr(model, "_h"):
-            raise TypeError("DeviceEnsembleSampler needs a golemflavor_amd LnProb / Model")
-        if model.ndim != dim:
-            raise AssertionError("dim %d does not match the model's %d parameters" % (dim, model.ndim))
+        multi = isinstance(lnpostfn, (list, tuple))
+        fns = list(lnpostfn) if multi else [lnpostfn]
+        models = [getattr(f, "model", f) for f in fns]
+        if multi:
+            if not models:
+                raise ValueError("empty list of posteriors")
+            if nchains not in (1, len(models)):
+                raise ValueError("nchains=%d but %d posteriors given" % (nchains, len(models)))
+            nchains = len(models)
+        for model in models:
+            if not hasattr(model, "_h"):
+                raise TypeError("DeviceEnsembleSampler needs a golemflavor_amd LnProb / Model")
+            if model.ndim != dim:
+                raise AssertionError("dim %d does not match the model's %d parameters" % (dim, model.ndim))
+        model, lnpostfn = models[0], fns[0]
         if nwalkers % 2:
             raise AssertionError("The number of walkers must be even.")
         if nwalkers < 2 * dim:
@@ -209,9 +221,15 @@ class DeviceEnsembleSampler:
         self._C, self._lib, self._L = C, _lib, _lib.lib()
         self.model, self.lnprobfn = model, lnpostfn
         self.k, self.dim, self.a, self.nchains = int(nwalkers), int(dim), float(a), int(nchains)
+        self.models = models if multi else None               # one posterior per chain (kept alive here)
         h = C.c_void_p()
-        _lib.check(self._L.gf_sampler_create(model._h, self.nchains, self.k, int(seed), self.a, C.byref(h)),
-                   "gf_sampler_create")
+        if multi:
+            handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in models])
+            _lib.check(self._L.gf_sampler_create_multi(handles, self.nchains, self.k, int(seed), self.a, C.byref(h)),
+                       "gf_sampler_create_multi")
+        else:
+            _lib.check(self._L.gf_sampler_create(model._h, self.nchains, self.k, int(seed), self.a, C.byref(h)),
+                       "gf_sampler_create")
         self._h = h
         self._have_state = False
         self.on_nonunitary = getattr(lnpostfn, "on_nonunitary", "raise")
@@ -324,30 +342,48 @@ class DeviceEnsembleSampler:
         nacc = self._fetch()[2].astype(np.float64) / max(self.iterations, 1)
         return nacc[0] if self.nchains == 1 else nacc
 
-    def postprocess(self, want_fr=True, want_status=False, nbins=None):
+    def postprocess(self, want_fr=True, want_status=False, nbins=None, models=None, step_major=False):
         """Chain post-processing on the device: the measured composition of every stored sample
         (scripts/mc_unitary.py:189-193, mc_texture.py:216-221) and/or its flavor histogram
         (golemflavor/plot.py:365-370).  Returns a dict with 'fr' (nwalkers, nsteps, 3), 'status',
-        'hist' (nbins, nbins, nbins) -- each with a leading chain axis when nchains > 1."""
+        'hist' (nbins, nbins, nbins) -- each with a leading chain axis when nchains > 1.
+
+        models: one Model / LnProb per chain to propagate with instead of the sampled posterior
+        (mc_texture.py samples the priors and propagates with the grid point's texture model).
+        step_major: leave 'fr' / 'status' in the device order (nsteps, nwalkers, ...), as `flat_steps`."""
         C = self._C
         ns = int(self._L.gf_sampler_nstored(self._h))
         fr = np.empty((self.nchains, ns, self.k, 3)) if want_fr else None
         st = np.empty((self.nchains, ns, self.k), dtype=np.int32) if want_status else None
         hist = np.zeros((self.nchains, nbins, nbins, nbins), dtype=np.uint64) if nbins else None
-        self._lib.check(self._L.gf_sampler_postprocess(
-            self._h, fr.ctypes.data_as(self._lib._dp) if want_fr else None,
+        handles = None
+        if models is not None:
+            ms = [getattr(m, "model", m) for m in models]
+            if len(ms) != self.nchains:
+                raise ValueError("%d post-processing models for %d chains" % (len(ms), self.nchains))
+            handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
+        self._lib.check(self._L.gf_sampler_postprocess_with(
+            self._h, handles, fr.ctypes.data_as(self._lib._dp) if want_fr else None,
             st.ctypes.data_as(self._lib._ip) if want_status else None, int(nbins or 0),
-            hist.ctypes.data_as(C.POINTER(C.c_uint64)) if nbins else None), "gf_sampler_postprocess")
+            hist.ctypes.data_as(C.POINTER(C.c_uint64)) if nbins else None), "gf_sampler_postprocess_with")
         out = {}
         if want_fr:
-            f = np.ascontiguousarray(fr.transpose(0, 2, 1, 3))
+            f = fr if step_major else np.ascontiguousarray(fr.transpose(0, 2, 1, 3))
             out["fr"] = f[0] if self.nchains == 1 else f
         if want_status:
-            t = np.ascontiguousarray(st.transpose(0, 2, 1))
+            t = st if step_major else np.ascontiguousarray(st.transpose(0, 2, 1))
             out["status"] = t[0] if self.nchains == 1 else t
         if nbins:
             out["hist"] = hist[0] if self.nchains == 1 else hist
         return out
+
+    def flat_steps(self):
+        """The stored samples in the order the device holds them, (nsteps*nwalkers, ndim) [leading chain axis
+        when nchains > 1]: `flatchain` without the transposition to emcee's walker-major order -- for
+        consumers that treat the chain as a bag of samples (histograms, post-processing)."""
+        c = self._fetch()[0]
+        c = c.reshape(self.nchains, -1, self.dim)
+        return c[0] if self.nchains == 1 else c
 
     @property
     def acor(self):

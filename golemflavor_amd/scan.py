@@ -2,9 +2,10 @@
 posterior of scripts/fr.py / sens.py's scale scan), sharded over one process per GPU.
 
 The reference runs one HTCondor job per grid point (submitter/mc_texture_dag.py:57-71,
-submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`) with the
-device-resident sampler; chains are gathered at the end (RCCL all-gather through `gf_comm_*`, or
-gloo / nothing for one rank).  No collective on the data path.
+submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`), and all grid points
+of a rank are stacked into ONE device-resident sampler -- one ensemble per posterior, one launch per
+half-step for all of them; chains are gathered at the end (RCCL all-gather through
+`gf_comm_*`, or gloo / nothing for one rank).  No collective on the data path.
 
     python -m golemflavor_amd.scan --config C4 [--nwalkers 2048 --burnin 100 --nsteps 200]
     python -m torch.distributed.run --nproc-per-node 8 ... -m golemflavor_amd.scan --config C5
@@ -40,25 +41,28 @@ class _TexturePoint:
 
     def __init__(self, point, g, *, dimension, texture, nwalkers, device, seed=25):
         self.scale, self.source = point
-        self.dimension, self.texture, self.device = dimension, texture, device
         self.ps6 = Cf.ParamSet(list(Cf.texture_paramset(dimension))[:6])       # scale fixed per grid point
-        self.prior = llh_utils.prior_ln_prob(self.ps6, device=device)
+        self.f = llh_utils.prior_ln_prob(self.ps6, device=device)
         rng = np.random.default_rng(seed + g)
         box = np.array(self.ps6.seeds, dtype=float)
         self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 6))        # mcmc.flat_seed, seeded per point
-        self.sampler = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, self.prior, seed=seed + g)
-
-    def collect(self):
-        samples = self.sampler.flatchain                                       # (nwalkers*nsteps, 6)
-        self.sampler.close()
-        self.prior.close()
-        desc = compile_model(self.ps6, "BSM_GAUSS", texture=self.texture, dimension=self.dimension,
+        self.ndim, self.nwalkers, self.seed = 6, nwalkers, seed + g
+        desc = compile_model(self.ps6, "BSM_GAUSS", texture=texture, dimension=dimension,
                              binning=Cf.default_bin_edges(), source_ratio=self.source, scale_fixed=self.scale,
                              bestfit_fr=(1 / 3,) * 3, smearing=0.02)
-        with Model(desc, device=self.device) as m:
-            frs, st = m.propagate(samples)
-        frs[st != 0] = np.nan                                                  # the reference would have raised there
-        return np.column_stack([frs, samples])
+        self.post_model = Model(desc, device=device)           # the chain is propagated with this one, on the device
+
+    def collect(self, samples, frs=None, status=None):
+        """samples: this point's flat chain (nwalkers*nsteps, 6); frs/status: its device post-processing"""
+        if frs is None:
+            frs, status = self.post_model.propagate(samples)
+        frs[status != 0] = np.nan                                              # the reference would have raised there
+        self.f.close()
+        self.post_model.close()
+        out = np.empty((samples.shape[0], 9))
+        out[:, :3] = frs
+        out[:, 3:] = samples
+        return out
 
 
 def sens_grid(n_scales=8, n_sources=8):
@@ -88,29 +92,70 @@ class _SensPoint:
         self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 12))
         lo, hi = Cf.SCALE_BOUNDARIES[dim]
         self.p0[:, 11] = np.clip(rng.normal(scale, 0.5, nwalkers), lo, hi)
-        self.sampler = mcmc_utils.DeviceEnsembleSampler(nwalkers, 12, self.f, seed=seed + g)
+        self.ndim, self.nwalkers, self.seed = 12, nwalkers, seed + g
 
-    def collect(self):
-        out = self.sampler.flatchain
-        self.sampler.close()
+    post_model = None
+
+    def collect(self, samples, frs=None, status=None):
         self.f.close()
-        return out
+        return samples
 
 
-def run_points(points, indices, make, burnin, nsteps):
-    """All of this rank's grid points advance together: every sampler enqueues its launches on its own
-    stream (run_async) before anybody waits, so small ensembles overlap on the GPU."""
+PHASES = {}          # wall-clock seconds of the last run_points call, by phase (reported by main)
+
+
+def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25):
+    """All of this rank's grid points advance together.  stacked (default): one sampler, one ensemble per
+    grid point's posterior, every half-step of every chain in one launch.  Otherwise one sampler per point,
+    each on its own stream (`run_async`), so that the small launches overlap on the GPU."""
+    t0 = time.perf_counter()
     jobs = {g: make(points[g], g) for g in indices}
-    for j in jobs.values():
-        j.sampler.run_async(j.p0, burnin, storechain=False)
-    for j in jobs.values():
-        j.sampler.wait()
-        j.sampler.reset()
-    for j in jobs.values():
-        j.sampler.run_async(None, nsteps)
-    for j in jobs.values():
-        j.sampler.wait()
-    return {g: j.collect() for g, j in jobs.items()}
+    if not jobs:
+        return {}
+    order = list(jobs)
+    first = jobs[order[0]]
+    PHASES.clear()
+    PHASES["setup"] = time.perf_counter() - t0
+    if stacked:
+        t0 = time.perf_counter()
+        sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed)
+        sampler.on_nonunitary = "-inf"
+        sampler.run_mcmc(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
+        sampler.reset()
+        sampler.run_mcmc(None, nsteps)
+        PHASES["sampling"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        flat = sampler.flat_steps()                               # (npoints, nsteps*nwalkers, ndim), device order
+        frs = sts = None
+        if first.post_model is not None:                          # mc_texture.py:216-221 on the device
+            post = sampler.postprocess(want_fr=True, want_status=True, step_major=True,
+                                       models=[jobs[g].post_model for g in order])
+            frs, sts = post["fr"].reshape(len(order), -1, 3), post["status"].reshape(len(order), -1)
+        if len(order) == 1:
+            flat = flat[None]
+        sampler.close()
+        PHASES["fetch"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = {g: jobs[g].collect(flat[i], None if frs is None else frs[i], None if sts is None else sts[i])
+               for i, g in enumerate(order)}
+        PHASES["collect"] = time.perf_counter() - t0
+        return out
+    samplers = {g: mcmc_utils.DeviceEnsembleSampler(j.nwalkers, j.ndim, j.f, seed=j.seed) for g, j in jobs.items()}
+    for g, sm in samplers.items():
+        sm.on_nonunitary = "-inf"
+        sm.run_async(jobs[g].p0, burnin, storechain=False)
+    for sm in samplers.values():
+        sm.wait()
+        sm.reset()
+    for sm in samplers.values():
+        sm.run_async(None, nsteps)
+    out = {}
+    for g, sm in samplers.items():
+        sm.wait()
+        flat = sm.flatchain
+        sm.close()
+        out[g] = jobs[g].collect(flat)
+    return out
 
 
 def main(argv=None):
@@ -123,6 +168,7 @@ def main(argv=None):
     ap.add_argument("--dimension", type=int, default=6)
     ap.add_argument("--texture", default="OET")
     ap.add_argument("--outfile", default=None, help="np.save the gathered chains here (rank 0)")
+    ap.add_argument("--no-stack", action="store_true", help="one sampler per grid point on its own stream (A/B)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,17 +194,20 @@ def main(argv=None):
         make = lambda p, g: _SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
         evals_per_point = nw * (a.burnin + a.nsteps)
     mine = gdist.shard(len(pts), backend.rank, backend.world)
-    local = run_points(pts, mine, make, a.burnin, a.nsteps)
+    local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=not a.no_stack)
+    t1 = time.perf_counter()
     chains = gdist.gather_chains(local, len(pts), backend)
+    PHASES["gather"] = time.perf_counter() - t1
     dt = time.perf_counter() - t0
     if rank == 0:
-        arr = np.stack(chains)
         if a.outfile:
-            mcmc_utils.save_chains(arr, a.outfile)
+            mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
-                          "nsteps": a.nsteps, "chains_shape": list(arr.shape), "seconds": dt,
+                          "nsteps": a.nsteps, "stacked": not a.no_stack,
+                          "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,
+                          "phases": {k: round(v, 4) for k, v in PHASES.items()},
                           "evals_per_s": len(pts) * evals_per_point / dt,
-                          "finite_fraction": float(np.mean(np.isfinite(arr)))}))
+                          "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}))
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()

@@ -174,6 +174,10 @@ int gf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);  /* synchroni
  * Philox4x32-10 keyed by `seed`.  One launch per half-ensemble update; the host sees chains at the end. */
 typedef struct gf_sampler gf_sampler;
 int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out);
+/* One ensemble per model (grid scans: submitter/sens_dag.py:75-95 and mc_texture_dag.py:57-71 run one job per
+ * grid point; here all of a GPU's grid points advance in one launch per half-step).  Chain ch samples the
+ * posterior of models[ch]; the models share device, ndim and mode and must outlive the sampler. */
+int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out);
 void gf_sampler_destroy(gf_sampler* s);
 /* p0 [nchains][nwalkers][ndim]; evaluates its lnprob on the device (mcmc.py:34 sampler.sample(p0, ...)) */
 int gf_sampler_set_state(gf_sampler* s, const double* pos);
@@ -193,6 +197,10 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
  * chain.  fr [nchains][nstored][nwalkers][3], status [nchains][nstored][nwalkers],
  * counts [nchains][nbins]^3; NULL = skip. */
 int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts);
+/* same, chain ch propagated with models[ch] (NULL: the sampling models): scripts/mc_texture.py samples the
+ * priors (:148-170) and pushes every sample through flux_averaged_BSMu of the grid point (:216-221) */
+int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
+                                uint64_t* counts);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only

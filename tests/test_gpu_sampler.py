@@ -18,7 +18,8 @@ def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0):
     nchains, nwalkers, ndim = p0.shape
     nhalf = nwalkers // 2
     pos = p0.copy()
-    lnp = np.stack([oracle.lnprob_batch(om, pos[c]) for c in range(nchains)])
+    oms = list(om) if isinstance(om, (list, tuple)) else [om] * nchains      # one posterior per chain, or one for all
+    lnp = np.stack([oracle.lnprob_batch(oms[c], pos[c]) for c in range(nchains)])
     chain = np.empty((nchains, nsteps, nwalkers, ndim))
     nacc = np.zeros((nchains, nwalkers), dtype=int)
     key = (seed & 0xffffffff, seed >> 32)
@@ -39,7 +40,7 @@ def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0):
                     zz[k] = zr * zr / a
                     cj, sk = pos[c, cbase + j], pos[c, half * nhalf + k]
                     q[k] = cj - zz[k] * (cj - sk)
-                lq = oracle.lnprob_batch(om, q)
+                lq = oracle.lnprob_batch(oms[c], q)
                 lk = lnp[c, half * nhalf:(half + 1) * nhalf]
                 with np.errstate(all="ignore"):
                     acc = np.log(zz ** (ndim - 1) / u3) > lk - lq
@@ -79,6 +80,77 @@ def test_device_sampler_equals_reference_stretch_move(golden, oracle):
     for x in (s, s2, s3):
         x.close()
     f.close()
+
+
+def test_stacked_grid_sampler_one_posterior_per_chain(golden, oracle):
+    """all grid points of a GPU advance in one launch per half-step, each chain with its own
+    posterior (here: three best-fit points / smearings of the notebook posterior)."""
+    _, ps = notebook_sets(golden)
+    from golemflavor_amd.descriptor import compile_model
+    from golemflavor_amd.model import Model
+    pts = [((1 / 3, 1 / 3, 1 / 3), 0.02), ((0.2, 0.45, 0.35), 0.05), ((0.5, 0.3, 0.2), 0.01)]
+    models = [Model(compile_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=sm)) for bf, sm in pts]
+    oms = [oracle.make_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=sm) for bf, sm in pts]
+    rng = np.random.default_rng(8)
+    nwalkers, nsteps, seed = 32, 10, 77
+    p0 = np.stack([uniform_theta(ps, nwalkers, rng, seeds=True) for _ in pts])
+    s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, models, seed=seed)
+    assert s.nchains == 3
+    s.run_mcmc(p0, nsteps)
+    ref_chain, ref_lnp, ref_acc = _reference_stretch(oracle, oms, p0, nsteps, seed)
+    assert np.abs(s.chain.transpose(0, 2, 1, 3) - ref_chain).max() < 1e-12
+    assert np.array_equal(np.round(s.acceptance_fraction * nsteps).astype(int), ref_acc)
+    assert np.allclose(s.state[1], ref_lnp, rtol=1e-12)
+    # the stored lnprob of chain ch is model ch's evaluation of the stored positions, bit for bit
+    for ch, m in enumerate(models):
+        again = m.lnprob(s.chain[ch].reshape(-1, 6), want_status=False).reshape(nwalkers, nsteps)
+        assert np.array_equal(again, s.lnprobability[ch])
+    # post-processing uses each chain's own model as well
+    post = s.postprocess(want_fr=True)
+    for ch, om in enumerate(oms):
+        ref_fr, _ = oracle.propagate_batch(om, s.chain[ch].reshape(-1, 6))
+        assert np.abs(post["fr"][ch].reshape(-1, 3) - ref_fr).max() < 1e-10
+    # identical posteriors in every chain: same chain as the nchains form of the sampler
+    s1 = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, [models[0]] * 3, seed=seed)
+    s2 = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, models[0], nchains=3, seed=seed)
+    s1.run_mcmc(p0, 40)
+    s2.run_mcmc(p0, 40)                                          # 40 steps: the hipGraph path too
+    assert np.array_equal(s1.chain, s2.chain) and np.array_equal(s1.lnprobability, s2.lnprobability)
+    for x in (s, s1, s2):
+        x.close()
+    # mismatched posteriors are refused
+    m4 = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)))
+    with pytest.raises(AssertionError):
+        mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, [models[0], m4])
+    mp = Model(compile_model(ps, "PRIOR_ONLY"))
+    with pytest.raises(_lib.GolemHipError):
+        mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, [models[0], mp])          # same ndim, other mode
+    for m in models + [m4, mp]:
+        m.close()
+
+
+def test_stacked_grid_sampler_bsm_grid_points():
+    """Chains with different texture / dimension / source / scale seeding in one sampler (the C5 grid)."""
+    from golemflavor_amd import scan
+    pts = scan.sens_grid(n_scales=2, n_sources=2)                  # 2 dims x 2 textures x 2 sources x 2 scales = 16
+    jobs = [scan._SensPoint(p, g, nwalkers=64, device=0, smearing=0.3) for g, p in enumerate(pts)]
+    s = mcmc_utils.DeviceEnsembleSampler(64, 12, [j.f for j in jobs], seed=5)
+    s.on_nonunitary = "-inf"
+    p0 = np.stack([j.p0 for j in jobs])
+    s.run_mcmc(p0, 40)
+    ch, lp = s.chain, s.lnprobability                               # (16, 64, 40, 12), (16, 64, 40)
+    assert ch.shape == (16, 64, 40, 12)
+    for g, j in enumerate(jobs):
+        again = j.f.model.lnprob(ch[g].reshape(-1, 12), want_status=False).reshape(64, 40)
+        fin = np.isfinite(lp[g])
+        assert fin.mean() > 0.5, (g, fin.mean())
+        assert np.array_equal(again[fin], lp[g][fin])
+    # the 16 posteriors differ: so do the chains' final lnprob levels
+    assert len({float(np.round(np.nanmax(np.where(np.isfinite(x), x, np.nan)), 6)) for x in lp}) > 4
+    assert 0.02 < s.acceptance_fraction.mean() < 0.9
+    s.close()
+    for j in jobs:
+        j.f.close()
 
 
 def test_device_sampler_bookkeeping_and_reset(golden):
@@ -197,6 +269,21 @@ def test_chain_postprocessing_on_device(golden, oracle):
         want, _ = np.histogramdd(post["fr"][c].reshape(-1, 3), bins=(nb, nb, nb), range=((0, 1),) * 3)
         assert np.array_equal(post["hist"][c], want.astype(np.uint64))     # plot.py:365-370
         assert post["hist"][c].sum() == 64 * 100
+    # propagate each chain with ANOTHER model than it was sampled with (mc_texture.py:216-221): per-chain source
+    srcs = [np.array([1., 0., 0.]), np.array([0., 1., 0.])]
+    pms = [Model(compile_model(ps, "PRIOR_ONLY", source_ratio=x)) for x in srcs]
+    post2 = s.postprocess(want_fr=True, models=pms, step_major=True)
+    flat = s.flat_steps()                                         # (2, 100*64, 4), same order as post2
+    assert post2["fr"].shape == (2, 100, 64, 3) and flat.shape == (2, 6400, 4)
+    assert np.array_equal(np.sort(flat[0], axis=0), np.sort(s.flatchain[0], axis=0))
+    for c, x in enumerate(srcs):
+        ref2, _ = oracle.propagate_batch(oracle.make_model(ps, "PRIOR_ONLY", source_ratio=x), flat[c])
+        assert np.abs(post2["fr"][c].reshape(-1, 3) - ref2).max() < 1e-10
+    assert np.abs(post2["fr"][0] - post2["fr"][1]).max() > 0.05
+    with pytest.raises(ValueError):
+        s.postprocess(models=pms[:1])
+    for x in pms:
+        x.close()
     # stand-alone histogram entry point, edge cases: 1.0 lands in the last bin, outside / NaN dropped
     pts = np.array([[0., 0., 1.], [1., 0., 0.], [0.5, 0.5, 0.], [1.0000001, 0., 0.], [-1e-9, .5, .5], [np.nan, .1, .9],
                     [1 / 3, 1 / 3, 1 / 3]])
