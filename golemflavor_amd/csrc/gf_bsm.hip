@@ -34,8 +34,11 @@
 namespace {
 using namespace gfdev;
 
+#ifndef GF_BSM_WAVES
+#define GF_BSM_WAVES 2
+#endif
 template <int NDIM, bool WITH_LLH, bool CHECK_UNI>
-__global__ __launch_bounds__(GF_BLOCK, 2) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
+__global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,

@@ -54,28 +54,97 @@ static __device__ __attribute__((noinline)) void mixing_cols12(double s12_2, dou
     c2r[2] = c23 * c13;            c2i[2] = 0.0;
 }
 
-// One energy bin: eigenvalues of the trace-normalised H by the trigonometric cubic solution
-// (fr.py:204-214 with a = -1), moduli by the eigenvector-eigenvalue identity.  Optionally the
-// reference's eigenvector form for the unitarity status.
-template <bool CHECK_UNI>
-__device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], double& residual)
+// ---- per-walker invariants -------------------------------------------------------------------------
+// H(E) = u S + v N (u = 1/2E, v = E^(d-3)) divided by its trace is the one-parameter family
+//     H' = a S' + t N',   S' = S / tr S,  N' = N / tr N,  a = u tr S / (u tr S + v tr N),  t = 1 - a,
+// so everything the bin needs that is polynomial in the entries of H' is a polynomial in (a, t) whose
+// coefficients depend on the walker only:
+//     b   = sum of principal 2x2 minors = a^2 b(S') + a t b(S',N') + t^2 b(N')            (fr.py:205)
+//     det = a t (a m1 + t m2),  m1 = tr(adj(S') N'),  m2 = tr(adj(N') S')                  (fr.py:206)
+//           (det S' = det N' = 0: both terms carry a zero eigenvalue, diag(0, ., .) in fr.py:383-393)
+//     h_aa = a S'_aa + t N'_aa,   sum_{b != a} |h_ab|^2 = a^2 qS_a + a t qX_a + t^2 qN_a.
+// These sums are at least as well conditioned as the products of entries they replace (b and det are sums
+// of non-negative terms for positive semi-definite S', N') and cost ~40 fewer fp64 instructions per bin.
+struct BinInv {
+    double trS, trN;
+    double bS, bSN, bN, m1, m2;
+    double sd0, sd1, nd0, nd1;
+    double qS0, qX0, qN0, qS1, qX1, qN1;
+};
+
+__device__ __forceinline__ Herm3 scaled(const Herm3& x, double s)
 {
-    const double s = fast_rcp((h_in.d0 + h_in.d1) + h_in.d2);
-    const double d0 = h_in.d0 * s, d1 = h_in.d1 * s, d2 = h_in.d2 * s;
-    const double r01 = h_in.r01 * s, i01 = h_in.i01 * s;
-    const double r02 = h_in.r02 * s, i02 = h_in.i02 * s;
-    const double r12 = h_in.r12 * s, i12 = h_in.i12 * s;
-    const double o01 = fma(r01, r01, i01 * i01);
-    const double o02 = fma(r02, r02, i02 * i02);
-    const double o12 = fma(r12, r12, i12 * i12);
-    // b = sum of principal 2x2 minors = (tr^2 - tr H^2)/2 (fr.py:205); c = -det (fr.py:206)
-    const double b = (fma(d0, d1, fma(d0, d2, d1 * d2)) - o01) - (o02 + o12);
-    // Re(h01 h12 conj(h02))
-    const double tr_re = fma(r01, r12, -i01 * i12), tr_im = fma(r01, i12, i01 * r12);
-    const double re3 = fma(tr_re, r02, tr_im * i02);
-    const double det = fma(d0 * d1, d2, 2.0 * re3) - fma(d0, o12, fma(d1, o02, d2 * o01));
-    const double Q = fma(-3.0, b, 1.0) * (1.0 / 9.0);                 // (a^2 - 3b)/9, a = -1
-    const double R = (fma(9.0, b, -2.0) - 27.0 * det) * (1.0 / 54.0); // (2a^3 - 9ab + 27c)/54
+    Herm3 y;
+    y.d0 = x.d0 * s; y.d1 = x.d1 * s; y.d2 = x.d2 * s;
+    y.r01 = x.r01 * s; y.i01 = x.i01 * s; y.r02 = x.r02 * s; y.i02 = x.i02 * s; y.r12 = x.r12 * s; y.i12 = x.i12 * s;
+    return y;
+}
+
+__device__ __forceinline__ double abs2(double re, double im) { return fma(re, re, im * im); }
+
+// sum of the principal 2x2 minors of a Hermitian 3x3
+__device__ __forceinline__ double minor_sum(const Herm3& x)
+{
+    return (fma(x.d0, x.d1, -abs2(x.r01, x.i01)) + fma(x.d0, x.d2, -abs2(x.r02, x.i02))) + fma(x.d1, x.d2, -abs2(x.r12, x.i12));
+}
+
+// tr(adj(X) Y) for Hermitian X, Y: the coefficient of x^2 y in det(x X + y Y)
+__device__ __forceinline__ double tr_adj(const Herm3& X, const Herm3& Y)
+{
+    const double a00 = fma(X.d1, X.d2, -abs2(X.r12, X.i12));
+    const double a11 = fma(X.d0, X.d2, -abs2(X.r02, X.i02));
+    const double a22 = fma(X.d0, X.d1, -abs2(X.r01, X.i01));
+    const double a01r = fma(X.r02, X.r12, X.i02 * X.i12) - X.r01 * X.d2;      // X02 conj(X12) - X01 X22
+    const double a01i = fma(X.i02, X.r12, -X.r02 * X.i12) - X.i01 * X.d2;
+    const double a02r = fma(X.r01, X.r12, -X.i01 * X.i12) - X.r02 * X.d1;     // X01 X12 - X02 X11
+    const double a02i = fma(X.r01, X.i12, X.i01 * X.r12) - X.i02 * X.d1;
+    const double a12r = fma(X.r02, X.r01, X.i02 * X.i01) - X.d0 * X.r12;      // X02 conj(X01) - X00 X12
+    const double a12i = fma(X.i02, X.r01, -X.r02 * X.i01) - X.d0 * X.i12;
+    const double diag = fma(a00, Y.d0, fma(a11, Y.d1, a22 * Y.d2));
+    const double off = fma(a01r, Y.r01, a01i * Y.i01) + fma(a02r, Y.r02, a02i * Y.i02) + fma(a12r, Y.r12, a12i * Y.i12);
+    return fma(2.0, off, diag);
+}
+
+// S, N -> normalised Sn, Nn and the invariants
+__device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, Herm3& Sn, Herm3& Nn, BinInv& w)
+{
+    w.trS = (S.d0 + S.d1) + S.d2;
+    w.trN = (N.d0 + N.d1) + N.d2;
+    Sn = scaled(S, fast_rcp(w.trS));
+    Nn = scaled(N, fast_rcp(w.trN));
+    w.bS = minor_sum(Sn);
+    w.bN = minor_sum(Nn);
+    const double x01 = fma(Sn.r01, Nn.r01, Sn.i01 * Nn.i01);                 // Re(S_ab conj(N_ab))
+    const double x02 = fma(Sn.r02, Nn.r02, Sn.i02 * Nn.i02);
+    const double x12 = fma(Sn.r12, Nn.r12, Sn.i12 * Nn.i12);
+    w.bSN = (fma(Sn.d0, Nn.d1, Sn.d1 * Nn.d0) + fma(Sn.d0, Nn.d2, Sn.d2 * Nn.d0)) + fma(Sn.d1, Nn.d2, Sn.d2 * Nn.d1) -
+            2.0 * ((x01 + x02) + x12);
+    w.m1 = tr_adj(Sn, Nn);
+    w.m2 = tr_adj(Nn, Sn);
+    w.sd0 = Sn.d0; w.sd1 = Sn.d1; w.nd0 = Nn.d0; w.nd1 = Nn.d1;
+    const double s01 = abs2(Sn.r01, Sn.i01), s02 = abs2(Sn.r02, Sn.i02), s12 = abs2(Sn.r12, Sn.i12);
+    const double n01 = abs2(Nn.r01, Nn.i01), n02 = abs2(Nn.r02, Nn.i02), n12 = abs2(Nn.r12, Nn.i12);
+    w.qS0 = s01 + s02; w.qS1 = s01 + s12;
+    w.qN0 = n01 + n02; w.qN1 = n01 + n12;
+    w.qX0 = 2.0 * (x01 + x02); w.qX1 = 2.0 * (x01 + x12);
+}
+
+// One energy bin: eigenvalues of the trace-normalised H by the trigonometric cubic solution
+// (fr.py:204-214 with a = -1), moduli by the eigenvector-eigenvalue identity for the 2x2 block
+// (alpha, i) in {e, mu} x {0, 1}; the remaining five follow from the unit row and column sums of |U|^2.
+// Optionally the reference's eigenvector form for the unitarity status.
+template <bool CHECK_UNI>
+__device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
+                                           double p[3][3], double& residual)
+{
+    const double al = u * w.trS, be = v * w.trN;
+    const double s = fast_rcp(al + be);
+    const double a = al * s, t = be * s;
+    const double aa = a * a, at = a * t, tt = t * t;
+    const double b = fma(aa, w.bS, fma(at, w.bSN, tt * w.bN));
+    const double det = at * fma(a, w.m1, t * w.m2);
+    const double Q = fma(-3.0, b, 1.0) * (1.0 / 9.0);                 // (a^2 - 3b)/9 with a = -tr = -1
+    const double R = (fma(9.0, b, -2.0) - 27.0 * det) * (1.0 / 54.0); // (2a^3 - 9ab + 27c)/54, c = -det
     const double sq = fast_sqrt(Q);
     double x = R * fast_rcp(Q * sq);
     x = fmin(1.0, fmax(-1.0, x));
@@ -84,25 +153,39 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
     sincos_small(phi, &sp, &cp);
     const double m2 = -2.0 * sq;
     const double HS3 = 0.8660254037844386;                            // sqrt(3)/2
-    double E[3];
-    E[0] = fma(m2, cp, 1.0 / 3.0);                                    // fr.py:212
-    E[1] = fma(m2, fma(HS3, sp, -0.5 * cp), 1.0 / 3.0);               // cos(phi - 2pi/3), fr.py:213
-    E[2] = fma(m2, fma(-HS3, sp, -0.5 * cp), 1.0 / 3.0);              // cos(phi + 2pi/3), fr.py:214
-
-    const double os0 = o01 + o02, os1 = o01 + o12, os2 = o02 + o12;
-    const double dd[3] = {d0, d1, d2};
-    const double os[3] = {os0, os1, os2};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = (i + 1) % 3, k = (i + 2) % 3;
-        const double inv = fast_rcp((E[i] - E[j]) * (E[i] - E[k]));
-#pragma unroll
-        for (int a = 0; a < 3; ++a) p[a][i] = fma(dd[a] - E[j], dd[a] - E[k], os[a]) * inv;
-    }
+    const double A = 1.5 * cp, B = HS3 * sp;
+    const double E0 = fma(m2, cp, 1.0 / 3.0);                         // fr.py:212
+    const double E1 = fma(m2, B - 0.5 * cp, 1.0 / 3.0);               // cos(phi - 2pi/3), fr.py:213
+    const double E2 = fma(m2, -B - 0.5 * cp, 1.0 / 3.0);              // cos(phi + 2pi/3), fr.py:214
+    // eigenvalue gaps in closed form (no cancellation near a level crossing):
+    // E0 - E1 = m2 (A - B), E0 - E2 = m2 (A + B), E1 - E2 = 2 m2 B
+    const double g01 = m2 * (A - B), g02 = m2 * (A + B), g12 = 2.0 * (m2 * B);
+    const double r = fast_rcp((g01 * g02) * g12);
+    const double inv0 = g12 * r;                                      // 1 / ((E0 - E1)(E0 - E2))
+    const double inv1 = -(g02 * r);                                   // 1 / ((E1 - E2)(E1 - E0))
+    const double d0 = fma(a, w.sd0, t * w.nd0), d1 = fma(a, w.sd1, t * w.nd1);
+    const double os0 = fma(aa, w.qS0, fma(at, w.qX0, tt * w.qN0));
+    const double os1 = fma(aa, w.qS1, fma(at, w.qX1, tt * w.qN1));
+    p[0][0] = fma(d0 - E1, d0 - E2, os0) * inv0;
+    p[0][1] = fma(d0 - E2, d0 - E0, os0) * inv1;
+    p[1][0] = fma(d1 - E1, d1 - E2, os1) * inv0;
+    p[1][1] = fma(d1 - E2, d1 - E0, os1) * inv1;
+    p[0][2] = (1.0 - p[0][0]) - p[0][1];
+    p[1][2] = (1.0 - p[1][0]) - p[1][1];
+    p[2][0] = (1.0 - p[0][0]) - p[1][0];
+    p[2][1] = (1.0 - p[0][1]) - p[1][1];
+    p[2][2] = (1.0 - p[0][2]) - p[1][2];
 
     if (CHECK_UNI) {
         // fr.py:216-236 in fp64, then fr.py:489-494.  h10 = conj(h01) etc.
-        double f01r = 0, f01i = 0, f02r = 0, f02i = 0, f12r = 0, f12i = 0, trf = 0;
+        const double E[3] = {E0, E1, E2};
+        const double d2 = fma(a, Sn.d2, t * Nn.d2);
+        const double r01 = fma(a, Sn.r01, t * Nn.r01), i01 = fma(a, Sn.i01, t * Nn.i01);
+        const double r02 = fma(a, Sn.r02, t * Nn.r02), i02 = fma(a, Sn.i02, t * Nn.i02);
+        const double r12 = fma(a, Sn.r12, t * Nn.r12), i12 = fma(a, Sn.i12, t * Nn.i12);
+        // tr|XX^+| is the sum of the squared norms of the normalised eigenvectors: 3 up to one rounding whatever
+        // A, B, C are, so only the off-diagonal sum (fr.py:491) carries the signal; a NaN shows up there too.
+        double f01r = 0, f01i = 0, f02r = 0, f02i = 0, f12r = 0, f12i = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double e0 = d0 - E[k], e1 = d1 - E[k], e2 = d2 - E[k];
@@ -118,7 +201,6 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
             const double a2 = fma(Ar, Ar, Ai * Ai), b2 = fma(Br, Br, Bi * Bi), c2 = fma(Cr, Cr, Ci * Ci);
             const double S = fma(a2, b2, fma(a2, c2, b2 * c2));
             const double invS = fast_rcp(S);
-            trf += (fma(b2, c2, fma(a2, c2, a2 * b2))) * invS;          // = 1 up to rounding (and NaN)
             // conj(A) conj(B) = (Ar Br - Ai Bi) - i (Ar Bi + Ai Br)
             const double abr = fma(Ar, Br, -Ai * Bi), abi = -fma(Ar, Bi, Ai * Br);
             // (XX^+)_01 += conj(A)conj(B) |C|^2 / S
@@ -132,11 +214,9 @@ __device__ __forceinline__ void bin_moduli(const Herm3& h_in, double p[3][3], do
         }
         const double off = fast_sqrt(fma(f01r, f01r, f01i * f01i)) + fast_sqrt(fma(f02r, f02r, f02i * f02i)) +
                            fast_sqrt(fma(f12r, f12r, f12i * f12i));
-        const double rt = fabs(trf - 3.0);
-        const double rs = fabs(fma(2.0, off, trf) - 3.0);
-        double r = fmax(rt, rs);
-        if (rt != rt || rs != rs) r = gf_inf();                        // NaN fails the reference's test too
-        residual = fmax(residual, r);
+        double rr = 2.0 * off;                                         // |sum|XX^+| - 3| with the trace at 3
+        if (rr != rr) rr = gf_inf();                                   // NaN fails the reference's test too
+        residual = fmax(residual, rr);
     }
 }
 
@@ -169,22 +249,27 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         N.r02 = fma(sc1, ttab[10], sc2 * ttab[11]); N.i02 = fma(sc1, ttab[12], sc2 * ttab[13]);
         N.r12 = fma(sc1, ttab[14], sc2 * ttab[15]); N.i12 = fma(sc1, ttab[16], sc2 * ttab[17]);
     }
-    const double src[3] = {c.src_fixed[0], c.src_fixed[1], c.src_fixed[2]};
+    Herm3 Sn, Nn;
+    BinInv w;
+    bin_invariants(S, N, Sn, Nn, w);
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
     // src / sum(src) (fr.py:535): the E^gamma factor cancels, so the spectral index has no effect.
+    const double isrc = fast_rcp(c.src_fixed_sum);
+    const double s0 = c.src_fixed[0] * isrc, s1 = c.src_fixed[1] * isrc, s2 = c.src_fixed[2] * isrc;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int nb = tb->nbins;
     for (int k = 0; k < nb; ++k) {
-        const double u = tb->inv2e[k], v = tb->epow[k], w = tb->weight[k];
-        Herm3 H;
-        H.d0 = fma(u, S.d0, v * N.d0); H.d1 = fma(u, S.d1, v * N.d1); H.d2 = fma(u, S.d2, v * N.d2);
-        H.r01 = fma(u, S.r01, v * N.r01); H.i01 = fma(u, S.i01, v * N.i01);
-        H.r02 = fma(u, S.r02, v * N.r02); H.i02 = fma(u, S.i02, v * N.i02);
-        H.r12 = fma(u, S.r12, v * N.r12); H.i12 = fma(u, S.i12, v * N.i12);
-        double p[3][3], f[3];
-        bin_moduli<CHECK_UNI>(H, p, residual);
-        propagate(p, src, c.src_fixed_sum, f);                      // fr.py:451
-        a0 = fma(f[0], w, a0); a1 = fma(f[1], w, a1); a2 = fma(f[2], w, a2);   // fr.py:454
+        const double u = tb->inv2e[k], v = tb->epow[k], wk = tb->weight[k];
+        double p[3][3];
+        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual);
+        // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
+        const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
+        const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
+        const double w2 = fma(p[2][2], s2, fma(p[1][2], s1, p[0][2] * s0));
+        const double f0 = fma(p[0][2], w2, fma(p[0][1], w1, p[0][0] * w0));
+        const double f1 = fma(p[1][2], w2, fma(p[1][1], w1, p[1][0] * w0));
+        const double f2 = fma(p[2][2], w2, fma(p[2][1], w1, p[2][0] * w0));
+        a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1); a2 = fma(f2, wk, a2);       // fr.py:454
     }
     const double inv = fast_rcp((a0 + a1) + a2);                    // fr.py:457
     fr[0] = a0 * inv; fr[1] = a1 * inv; fr[2] = a2 * inv;

@@ -130,26 +130,43 @@ __device__ __forceinline__ double fast_cos_phase(double x, const double* k = nul
     return fma(u * z, q, u);
 }
 
+// Minimax / fdlibm coefficients of sincos_small and fast_acos in constant memory: read with uniform
+// addresses they arrive by scalar loads and feed v_fma_f64 as its one scalar operand.  As literals the
+// compiler keeps each in a VGPR pair across the BSM bin loop and copies it (v_mov_b64) in front of every
+// Horner step (v_fmac overwrites its addend): 22 extra instructions per bin, ~50 VGPRs.
+__constant__ double GF_KTAB[26] = {
+    // [0..7]  sin: odd minimax, highest order first
+    2.7117413873509064e-15, -7.641995277350052e-13, 1.605889634387573e-10, -2.505210587009456e-08,
+    2.75573191979119e-06, -0.00019841269841110079, 0.008333333333332799, -0.16666666666666657,
+    // [8..15] cos: even minimax, highest order first (the constant term 1 is applied last)
+    4.695137892341541e-14, -1.1468837412893726e-11, 2.0876733673699156e-09, -2.755731905787651e-07,
+    2.4801587300891894e-05, -0.0013888888888887252, 0.04166666666666665, -0.5,
+    // [16..21] asin numerator pS5..pS0, [22..25] denominator qS4..qS1 (fdlibm e_asin.c)
+    3.47933107596021167570e-05, 7.91534994289814532176e-04, -4.00555345006794114027e-02, 2.01212532134862925881e-01,
+    -3.25565818622400915405e-01, 1.66666666666666657415e-01,
+    7.70381505559019352791e-02, -6.88283971605453293030e-01, 2.02094576023350569471e+00, -2.40339491173441421878e+00};
+
 // sin and cos of phi in [0, 1.1] (the cubic solver's angle acos(x)/3 <= pi/3): no argument reduction;
 // odd / even minimax polynomials fitted in 50-digit arithmetic (abs error <= 2.3e-16 each).
 __device__ __forceinline__ void sincos_small(double u, double* sn, double* cs)
 {
+    const double* k = GF_KTAB;
     const double z = u * u;
-    double q = fma(z, 2.7117413873509064e-15, -7.641995277350052e-13);
-    q = fma(z, q, 1.605889634387573e-10);
-    q = fma(z, q, -2.505210587009456e-08);
-    q = fma(z, q, 2.75573191979119e-06);
-    q = fma(z, q, -0.00019841269841110079);
-    q = fma(z, q, 0.008333333333332799);
-    q = fma(z, q, -0.16666666666666657);
+    double q = fma(z, k[0], k[1]);
+    q = fma(z, q, k[2]);
+    q = fma(z, q, k[3]);
+    q = fma(z, q, k[4]);
+    q = fma(z, q, k[5]);
+    q = fma(z, q, k[6]);
+    q = fma(z, q, k[7]);
     *sn = fma(u * z, q, u);
-    double c = fma(z, 4.695137892341541e-14, -1.1468837412893726e-11);
-    c = fma(z, c, 2.0876733673699156e-09);
-    c = fma(z, c, -2.755731905787651e-07);
-    c = fma(z, c, 2.4801587300891894e-05);
-    c = fma(z, c, -0.0013888888888887252);
-    c = fma(z, c, 0.04166666666666665);
-    c = fma(z, c, -0.5);
+    double c = fma(z, k[8], k[9]);
+    c = fma(z, c, k[10]);
+    c = fma(z, c, k[11]);
+    c = fma(z, c, k[12]);
+    c = fma(z, c, k[13]);
+    c = fma(z, c, k[14]);
+    c = fma(z, c, k[15]);
     *cs = fma(z, c, 1.0);
 }
 
@@ -157,18 +174,19 @@ __device__ __forceinline__ void sincos_small(double u, double* sn, double* cs)
 // s = sqrt((1-|x|)/2)) written branch-free.  Abs error a few 1e-16 rad.
 __device__ __forceinline__ double fast_acos(double x)
 {
+    const double* k = GF_KTAB + 16;
     const double ax = fabs(x);
     const bool big = ax > 0.5;
     const double z = big ? fma(-0.5, ax, 0.5) : x * x;
     const double s = big ? fast_sqrt(z) : ax;
-    double p = fma(z, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
-    p = fma(z, p, -4.00555345006794114027e-02);
-    p = fma(z, p, 2.01212532134862925881e-01);
-    p = fma(z, p, -3.25565818622400915405e-01);
-    p = fma(z, p, 1.66666666666666657415e-01);
-    double q = fma(z, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
-    q = fma(z, q, 2.02094576023350569471e+00);
-    q = fma(z, q, -2.40339491173441421878e+00);
+    double p = fma(z, k[0], k[1]);
+    p = fma(z, p, k[2]);
+    p = fma(z, p, k[3]);
+    p = fma(z, p, k[4]);
+    p = fma(z, p, k[5]);
+    double q = fma(z, k[6], k[7]);
+    q = fma(z, q, k[8]);
+    q = fma(z, q, k[9]);
     q = fma(z, q, 1.0);
     const double r = (z * p) * fast_rcp(q);
     const double as = fma(s, r, s);                                  // asin(s)
