@@ -222,9 +222,16 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
 
 // flux_averaged_BSMu for one walker (fr.py:403-458).  Returns the normalised composition and the worst
 // unitarity residual over the bins.
-template <bool CHECK_UNI>
+//
+// LPW > 1 (device sampler on small ensembles): LPW adjacent lanes of one wave hold the SAME walker; each
+// computes the walker's invariants (redundantly, bit-identical) and the bins k = sub, sub + LPW, ...; the
+// per-bin compositions meet in LDS (`fgrp`: [nb][3] doubles + LPW residuals, private to the lane group) and
+// every lane then runs the same in-order weighted sum, so the result is bitwise the LPW = 1 result on all LPW
+// lanes.  The walker's critical path drops from nb bins to ceil(nb / LPW).
+template <bool CHECK_UNI, int LPW = 1>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
-                                             const double* row, double fr[3], double& residual)
+                                             const double* row, double fr[3], double& residual, int sub = 0,
+                                             double* fgrp = nullptr)
 {
     // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
     double c1r[3], c1i[3], c2r[3], c2i[3];
@@ -258,8 +265,8 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     const double s0 = c.src_fixed[0] * isrc, s1 = c.src_fixed[1] * isrc, s2 = c.src_fixed[2] * isrc;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int nb = tb->nbins;
-    for (int k = 0; k < nb; ++k) {
-        const double u = tb->inv2e[k], v = tb->epow[k], wk = tb->weight[k];
+    for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
+        const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
         bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual);
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
@@ -269,7 +276,27 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         const double f0 = fma(p[0][2], w2, fma(p[0][1], w1, p[0][0] * w0));
         const double f1 = fma(p[1][2], w2, fma(p[1][1], w1, p[1][0] * w0));
         const double f2 = fma(p[2][2], w2, fma(p[2][1], w1, p[2][0] * w0));
-        a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1); a2 = fma(f2, wk, a2);       // fr.py:454
+        if (LPW > 1) {
+            fgrp[3 * k] = f0; fgrp[3 * k + 1] = f1; fgrp[3 * k + 2] = f2;
+        } else {
+            const double wk = tb->weight[k];
+            a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1); a2 = fma(f2, wk, a2);   // fr.py:454
+        }
+    }
+    if (LPW > 1) {
+        if (CHECK_UNI) fgrp[3 * nb + sub] = residual;
+        // the lanes of a group sit in one wave: its LDS operations retire in order, the fence keeps the compiler honest
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < nb; ++k) {
+            const double wk = tb->weight[k];
+            a0 = fma(fgrp[3 * k], wk, a0); a1 = fma(fgrp[3 * k + 1], wk, a1); a2 = fma(fgrp[3 * k + 2], wk, a2);
+        }
+        if (CHECK_UNI) {
+#pragma unroll
+            for (int j = 0; j < LPW; ++j) residual = fmax(residual, fgrp[3 * nb + j]);
+        }
     }
     const double inv = fast_rcp((a0 + a1) + a2);                    // fr.py:457
     fr[0] = a0 * inv; fr[1] = a1 * inv; fr[2] = a2 * inv;

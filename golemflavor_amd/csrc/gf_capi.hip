@@ -449,10 +449,12 @@ int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, cons
 }
 
 // constants only: does not give the model a stream
-int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus)
+int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus,
+                       int* nbins)
 {
     if (!m) return GF_ERR_INVALID_ARG;
     *c = &m->c; *d_bsm = m->d_bsm; *d_ptab = m->d_ptab; *device = m->device; *cus = m->cus;
+    *nbins = m->c.mode == GF_MODE_BSM_GAUSS ? m->hb.nbins : 0;
     return GF_OK;
 }
 

@@ -75,6 +75,8 @@ struct StretchArgs {
     const GfCommon* commons;
     const GfBsm* const* tbs;
     const double* const* ptabs;
+    int32_t nbins_max;      // largest nbins over the chains' models (BSM); sizes the lane-group buffers
+    int32_t lpw;            // lanes per walker for this run (host-side dispatch only)
 };
 
 __global__ void k_tick(StepState* st, int nsteps)
@@ -84,9 +86,10 @@ __global__ void k_tick(StepState* st, int nsteps)
 }
 
 // lnprob of the proposal held in LDS row `row`
-template <int NDIM, int MODE>
+template <int NDIM, int MODE, int LPW>
 __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm* tb, const double* ctab,
-                                                  const double* ttab, const double* row, int ndim, int& st)
+                                                  const double* ttab, const double* row, int ndim, int& st, int sub,
+                                                  double* fgrp)
 {
     double val, fr[3];
     if (MODE == MODE_BSM_GAUSS) {
@@ -96,7 +99,7 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
         st = ST_OUT_OF_PRIOR;
         if (inbox) {
             double residual = 0.0;
-            flux_average<true>(c, tb, ttab, row, fr, residual);
+            flux_average<true, LPW>(c, tb, ttab, row, fr, residual, sub, fgrp);
             st = (residual < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;
@@ -109,10 +112,14 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
 
 // One half-ensemble update for the walkers of one block.  `chain` / `k` = this thread's ensemble and its
 // index in the active half (`valid` false for the padding threads of the last block of a chain).
-template <int NDIM, int MODE>
+// LPW > 1 (BSM posteriors on small ensembles): LPW adjacent lanes hold the same walker and split its energy
+// bins (flux_average); everything else they compute redundantly and identically, lane `sub == 0` writes.
+template <int NDIM, int MODE, int LPW>
 __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __restrict__ tb, const double* __restrict__ ptab,
-                                             const StretchArgs& s, const int chain, const int k, const bool valid)
+                                             const StretchArgs& s, const int chain, const int k, const bool valid, const int sub)
 {
+    extern __shared__ __attribute__((aligned(16))) double fdyn[];    // LPW > 1: per lane group [nbins_max][3] + [LPW]
+    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * (3 * s.nbins_max + LPW) : nullptr;
     constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * ND];
     __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
@@ -160,7 +167,7 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
         row[d] = fma(-z, cv - sk[d], cv);                    // q = c_j - z (c_j - s_k)
     }
     int st;
-    const double lnq = proposal_lnprob<NDIM, MODE>(c, tb, ctab, ttab, row, ndim, st);
+    const double lnq = proposal_lnprob<NDIM, MODE, LPW>(c, tb, ctab, ttab, row, ndim, st, sub, fgrp);
     const int64_t wi = (int64_t)chain * s.nwalkers + w;
     const double lnk = s.lnp[wi];
     // z^(ndim-1) / u3
@@ -170,8 +177,9 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
     bool accept = lhs > lnk - lnq;                           // false for NaN and for lnq = -inf
     if (st == ST_NON_UNITARY) {                              // the reference raises inside ln_prob here
         accept = false;
-        atomicAdd(s.flags, 1u);
+        if (sub == 0) atomicAdd(s.flags, 1u);
     }
+    if (LPW > 1 && sub != 0) return;                         // the group's results are identical: one writer
     if (accept) {
         double* dst = s.pos + wi * ndim;
 #pragma unroll
@@ -196,48 +204,75 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
 }
 
 // every ensemble samples the same posterior: constants by value (scalar registers), walkers packed densely
-template <int NDIM, int MODE>
+template <int NDIM, int MODE, int LPW>
 __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
                                                           const double* __restrict__ ptab, const StretchArgs s)
 {
     const int nhalf = s.nwalkers / 2;
-    const int64_t g = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x;
+    const int64_t g = t / LPW;
     const bool valid = g < (int64_t)s.nchains * nhalf;
     const int chain = valid ? (int)(g / nhalf) : 0;
     const int k = valid ? (int)(g - (int64_t)chain * nhalf) : 0;
-    stretch_body<NDIM, MODE>(c, tb, ptab, s, chain, k, valid);
+    stretch_body<NDIM, MODE, LPW>(c, tb, ptab, s, chain, k, valid, (int)(t % LPW));
 }
 
 // one posterior per ensemble (grid scans, SURVEY.md 8(e) "all chains of a GPU stacked into one launch"):
 // blockIdx.y = chain, so that a block's constants are block-uniform and come from scalar loads
-template <int NDIM, int MODE>
+template <int NDIM, int MODE, int LPW>
 __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch_multi(const StretchArgs s)
 {
     const int chain = blockIdx.y;
-    const int k = blockIdx.x * GF_BLOCK + threadIdx.x;
-    stretch_body<NDIM, MODE>(s.commons[chain], s.tbs[chain], s.ptabs[chain], s, chain, k, k < s.nwalkers / 2);
+    const int t = blockIdx.x * GF_BLOCK + threadIdx.x;
+    const int k = t / LPW;
+    stretch_body<NDIM, MODE, LPW>(s.commons[chain], s.tbs[chain], s.ptabs[chain], s, chain, k, k < s.nwalkers / 2, t % LPW);
+}
+
+// Lanes per walker for a BSM half-step of `walkers` proposals: the fewest of {1, 4, 16} that put at least
+// four waves on every SIMD (two resident at this kernel's register budget, two queued); small ensembles are
+// bound by one walker's critical path (nbins diagonalisations in a row), not by throughput.
+inline int lanes_per_walker(int mode, int64_t walkers, int nbins_max, int cus)
+{
+    if (mode != MODE_BSM_GAUSS || nbins_max < 2) return 1;
+    const char* force = std::getenv("GF_SAMPLER_LPW");                 // diagnostics / A-B, read per run
+    if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
+    const int64_t want = (int64_t)cus * 4 * 4;
+    for (int lpw : {1, 4, 16}) {
+        const size_t lds = (size_t)(GF_BLOCK / lpw) * (3 * nbins_max + lpw) * sizeof(double);
+        if (lpw > 1 && lds > 40 * 1024) return lpw == 4 ? 1 : 4;      // group buffers no longer fit beside the tiles
+        if ((walkers * lpw + GF_WAVE - 1) / GF_WAVE >= want || lpw == 16) return lpw;
+    }
+    return 1;
+}
+
+template <int NDIM, int MODE, int LPW>
+hipError_t launch_stretch_nml(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
+{
+    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * (3 * a.nbins_max + LPW) * sizeof(double) : 0;
+    if (a.commons) {
+        const dim3 grid((unsigned)(((int64_t)(a.nwalkers / 2) * LPW + GF_BLOCK - 1) / GF_BLOCK), a.nchains);
+        hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE, LPW>), grid, dim3(GF_BLOCK), lds, st, a);
+    } else {
+        const int64_t total = (int64_t)a.nchains * (a.nwalkers / 2) * LPW;
+        hipLaunchKernelGGL((k_stretch<NDIM, MODE, LPW>), dim3((unsigned)((total + GF_BLOCK - 1) / GF_BLOCK)), dim3(GF_BLOCK), lds, st,
+                           c, tb, ptab, a);
+    }
+    return hipGetLastError();
 }
 
 template <int NDIM>
 hipError_t launch_stretch_n(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
 {
-    if (a.commons) {
-        const dim3 grid((a.nwalkers / 2 + GF_BLOCK - 1) / GF_BLOCK, a.nchains);
-        switch (c.mode) {
-        case MODE_PRIOR_ONLY: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_PRIOR_ONLY>), grid, dim3(GF_BLOCK), 0, st, a); break;
-        case MODE_SM_GAUSS: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_SM_GAUSS>), grid, dim3(GF_BLOCK), 0, st, a); break;
-        default: hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE_BSM_GAUSS>), grid, dim3(GF_BLOCK), 0, st, a); break;
-        }
-        return hipGetLastError();
-    }
-    const int64_t total = (int64_t)a.nchains * (a.nwalkers / 2);
-    const int grid = (int)((total + GF_BLOCK - 1) / GF_BLOCK);
     switch (c.mode) {
-    case MODE_PRIOR_ONLY: hipLaunchKernelGGL((k_stretch<NDIM, MODE_PRIOR_ONLY>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
-    case MODE_SM_GAUSS: hipLaunchKernelGGL((k_stretch<NDIM, MODE_SM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
-    default: hipLaunchKernelGGL((k_stretch<NDIM, MODE_BSM_GAUSS>), dim3(grid), dim3(GF_BLOCK), 0, st, c, tb, ptab, a); break;
+    case MODE_PRIOR_ONLY: return launch_stretch_nml<NDIM, MODE_PRIOR_ONLY, 1>(c, tb, ptab, a, st);
+    case MODE_SM_GAUSS: return launch_stretch_nml<NDIM, MODE_SM_GAUSS, 1>(c, tb, ptab, a, st);
+    default:
+        switch (a.lpw) {
+        case 4: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 4>(c, tb, ptab, a, st);
+        case 16: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 16>(c, tb, ptab, a, st);
+        default: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 1>(c, tb, ptab, a, st);
+        }
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_stretch(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
@@ -261,6 +296,7 @@ struct gf_sampler {
     const GfBsm** d_tbs = nullptr;
     const double** d_ptabs = nullptr;
     int nchains = 0, nwalkers = 0, ndim = 0;
+    int cus = 256, nbins_max = 0;
     uint64_t seed = 0, iteration = 0;
     double a = 2.0;
     double* d_pos = nullptr;
@@ -282,7 +318,8 @@ struct gf_sampler {
 extern "C" {
 int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, void** stream,
                       int* device);
-int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus);
+int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus,
+                       int* nbins);
 int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
                        double* d_fr, int32_t* d_status);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
@@ -317,6 +354,10 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
     gf_sampler* s = new (std::nothrow) gf_sampler();
     if (!s) return GF_ERR_ALLOC;
     s->model = m; s->nchains = nchains; s->nwalkers = nwalkers; s->ndim = c->ndim; s->seed = seed; s->a = a;
+    {
+        const GfCommon* cc; const GfBsm* tbb; const double* pt; int dev;
+        gf_model_constants(m, &cc, &tbb, &pt, &dev, &s->cus, &s->nbins_max);
+    }
     const size_t nw = (size_t)nchains * nwalkers;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_pos, sizeof(double) * nw * s->ndim);
@@ -366,6 +407,7 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
         if (!models[ch]) return GF_ERR_INVALID_ARG;
     const GfCommon* c0; const GfBsm* tb0; const double* ptab0; void* stream0; int device0;
     if (gf_model_internal(models[0], &c0, &tb0, &ptab0, &stream0, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    int nbins_max = 0;
     GfCommon* hc = new (std::nothrow) GfCommon[nchains];
     const GfBsm** htb = new (std::nothrow) const GfBsm*[nchains];
     const double** hpt = new (std::nothrow) const double*[nchains];
@@ -373,8 +415,8 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
     auto cleanup = [&]() { delete[] hc; delete[] htb; delete[] hpt; };
     if (!hc || !htb || !hpt || !keep) { cleanup(); delete[] keep; return GF_ERR_ALLOC; }
     for (int ch = 0; ch < nchains; ++ch) {
-        const GfCommon* c; int device, cus;
-        if (gf_model_constants(models[ch], &c, &htb[ch], &hpt[ch], &device, &cus) != GF_OK || device != device0 ||
+        const GfCommon* c; int device, cus, nbins;
+        if (gf_model_constants(models[ch], &c, &htb[ch], &hpt[ch], &device, &cus, &nbins) != GF_OK || device != device0 ||
             c->ndim != c0->ndim || c->mode != c0->mode) {
             std::snprintf(g_serr, sizeof(g_serr), "gf_sampler_create_multi: model %d differs from model 0 in device, ndim or mode", ch);
             cleanup(); delete[] keep;
@@ -382,11 +424,13 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
         }
         hc[ch] = *c;
         keep[ch] = models[ch];
+        if (nbins > nbins_max) nbins_max = nbins;
     }
     gf_sampler* s = nullptr;
     int rc = gf_sampler_create(models[0], nchains, nwalkers, seed, a, &s);
     if (rc != GF_OK) { cleanup(); delete[] keep; return rc; }
     s->models = keep;
+    s->nbins_max = nbins_max;
     hipError_t e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_tbs, sizeof(void*) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*) * nchains);
@@ -484,6 +528,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     a.lnp_chain = store ? s->d_lnp_chain : nullptr;
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
     a.commons = s->d_commons; a.tbs = s->d_tbs; a.ptabs = s->d_ptabs;
+    a.nbins_max = s->nbins_max;
+    a.lpw = lanes_per_walker(c->mode, (int64_t)s->nchains * (s->nwalkers / 2), s->nbins_max, s->cus);
     auto steps = [&](int count) -> hipError_t {       // `count` steps relative to the current base, then tick
         for (int i = 0; i < count; ++i) {
             a.step_offset = i;
@@ -604,8 +650,8 @@ int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* 
     int cus = 256;
     for (int ch = 0; ch < s->nchains; ++ch) {
         gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
-        const GfCommon* c; int device;
-        if (gf_model_constants(mc, &c, &tb, &ptab, &device, &cus) != GF_OK || c->ndim != s->ndim || device != device0)
+        const GfCommon* c; int device, nbins;
+        if (gf_model_constants(mc, &c, &tb, &ptab, &device, &cus, &nbins) != GF_OK || c->ndim != s->ndim || device != device0)
             return GF_ERR_INVALID_ARG;
     }
     GFS_HIP(hipSetDevice(device0));

@@ -153,6 +153,31 @@ def test_stacked_grid_sampler_bsm_grid_points():
         j.f.close()
 
 
+def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
+    """Small BSM ensembles split a walker's energy bins over 4 or 16 lanes (critical path nbins -> nbins/LPW);
+    the in-order weighted sum makes the chain bitwise independent of that choice."""
+    asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
+    args = bsm_args(6, Texture.OET, (0., 1., 0.))
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.3, on_nonunitary="-inf")
+    rng = np.random.default_rng(12)
+    p0 = np.stack([uniform_theta(ps, 48, rng, seeds=True) for _ in range(3)])
+    p0[:, :, 11] = rng.uniform(-52, -40, (3, 48))
+    chains = {}
+    for lpw in ("1", "4", "16"):
+        monkeypatch.setenv("GF_SAMPLER_LPW", lpw)
+        s = mcmc_utils.DeviceEnsembleSampler(48, 12, f, nchains=3, seed=21)
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 36)                                      # 32 steps through the graph + 4 eager
+        chains[lpw] = (s.chain, s.lnprobability, s.acceptance_fraction)
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_LPW")
+    for lpw in ("4", "16"):
+        for x, y in zip(chains["1"], chains[lpw]):
+            assert np.array_equal(x, y, equal_nan=True), lpw
+    assert np.isfinite(chains["1"][1]).mean() > 0.5 and 0.05 < chains["1"][2].mean() < 0.9
+    f.close()
+
+
 def test_device_sampler_bookkeeping_and_reset(golden):
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)
