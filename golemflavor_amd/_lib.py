@@ -92,6 +92,7 @@ SIGNATURES = {
     "gf_sampler_iterations": (C.c_int64, [_vp]),
     "gf_sampler_get_state": (C.c_int, [_vp, _dp, _dp]),
     "gf_sampler_get_chain": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gf_sampler_walker_mean": (C.c_int, [_vp, _dp]),
     "gf_sampler_postprocess": (C.c_int, [_vp, _dp, _ip, C.c_int, C.POINTER(C.c_uint64)]),
     "gf_sampler_postprocess_with": (C.c_int, [_vp, C.POINTER(_vp), _dp, _ip, C.c_int, C.POINTER(C.c_uint64)]),
     "gf_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

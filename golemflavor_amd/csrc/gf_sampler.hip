@@ -260,6 +260,33 @@ hipError_t launch_stretch_nml(const GfCommon& c, const GfBsm* tb, const double* 
     return hipGetLastError();
 }
 
+// Ensemble mean of every stored step: chain [nchains][cap][nwalkers][ndim] -> mean [nchains][nstored][ndim]
+// (the series emcee's acor works on, golemflavor/mcmc.py:45-51).  One block per (step, chain); thread t sums
+// the elements t, t + 256, ... of the step's contiguous nwalkers x ndim block whose column is (t mod ndim)
+// -- 256 mod ndim must be 0 for that, otherwise threads stride by the largest multiple of ndim <= 256 -- then
+// a fixed LDS tree: deterministic, coalesced, one pass over the chain at HBM rate.
+__global__ __launch_bounds__(GF_BLOCK) void k_walker_mean(const double* __restrict__ chain, int64_t cap, int64_t nstored,
+                                                          int nwalkers, int ndim, double* __restrict__ mean)
+{
+    __shared__ double part[GF_BLOCK];
+    const int64_t step = blockIdx.x;
+    const int ch = blockIdx.y;
+    const double* src = chain + ((int64_t)ch * cap + step) * nwalkers * ndim;
+    const int stride = (GF_BLOCK / ndim) * ndim;            // threads in use; a multiple of ndim
+    const int n = nwalkers * ndim;
+    double acc = 0.0;
+    if ((int)threadIdx.x < stride)
+        for (int i = threadIdx.x; i < n; i += stride) acc += src[i];
+    part[threadIdx.x] = (int)threadIdx.x < stride ? acc : 0.0;
+    __syncthreads();
+    // thread d < ndim folds the partial sums of its column in a fixed order
+    if ((int)threadIdx.x < ndim) {
+        double sum = 0.0;
+        for (int t = threadIdx.x; t < stride; t += ndim) sum += part[t];
+        mean[((int64_t)ch * nstored + step) * ndim + threadIdx.x] = sum / (double)nwalkers;
+    }
+}
+
 template <int NDIM>
 hipError_t launch_stretch_n(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
 {
@@ -623,6 +650,30 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
     }
     if (naccepted) GFS_HIP(hipMemcpy(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost));
     if (nonunitary) GFS_HIP(hipMemcpy(nonunitary, s->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GF_OK;
+}
+
+// mean [nchains][nstored][ndim]: the ensemble-averaged series whose integrated autocorrelation time the
+// reference prints (golemflavor/mcmc.py:45-51 sampler.acor); reduced on the device, only the means cross PCIe.
+int gf_sampler_walker_mean(gf_sampler* s, double* mean)
+{
+    if (!s || !mean) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (s->nstored == 0) { GFS_HIP(hipStreamSynchronize(st)); return GF_OK; }
+    const size_t bytes = sizeof(double) * (size_t)s->nchains * s->nstored * s->ndim;
+    double* d_mean = nullptr;
+    GFS_HIP(hipMalloc((void**)&d_mean, bytes));
+    hipLaunchKernelGGL(k_walker_mean, dim3((unsigned)s->nstored, (unsigned)s->nchains), dim3(GF_BLOCK), 0, st, s->d_chain,
+                       s->nstore_cap, s->nstored, s->nwalkers, s->ndim, d_mean);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(mean, d_mean, bytes, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_mean);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return sfail(e, "gf_sampler_walker_mean");
     return GF_OK;
 }
 

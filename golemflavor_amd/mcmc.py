@@ -389,11 +389,19 @@ class DeviceEnsembleSampler:
     def acor(self):
         return self.get_autocorr_time()
 
+    def walker_mean(self):
+        """Ensemble mean of every stored step, (nsteps, ndim) [leading chain axis when nchains > 1],
+        reduced on the device: only nsteps x ndim numbers cross PCIe."""
+        ns = int(self._L.gf_sampler_nstored(self._h))
+        out = np.empty((self.nchains, ns, self.dim))
+        self._lib.check(self._L.gf_sampler_walker_mean(self._h, out.ctypes.data_as(self._lib._dp)), "gf_sampler_walker_mean")
+        return out[0] if self.nchains == 1 else out
+
     def get_autocorr_time(self, c=5, tol=50):
-        ch = self.chain
+        m = self.walker_mean()                                 # emcee-2: acor of the ensemble-averaged chain
         if self.nchains == 1:
-            return integrated_time(np.mean(ch, axis=0), c=c, tol=tol)
-        return np.array([integrated_time(np.mean(x, axis=0), c=c, tol=tol) for x in ch])
+            return integrated_time(m, c=c, tol=tol)
+        return np.array([integrated_time(x, c=c, tol=tol) for x in m])
 
     def close(self):
         if getattr(self, "_h", None) is not None:

@@ -196,6 +196,9 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
  * golemflavor/plot.py:365-370): composition of every stored sample and/or its [nbins]^3 histogram per
  * chain.  fr [nchains][nstored][nwalkers][3], status [nchains][nstored][nwalkers],
  * counts [nchains][nbins]^3; NULL = skip. */
+/* mean [nchains][nstored][ndim]: ensemble mean of every stored step, the series behind sampler.acor
+ * (golemflavor/mcmc.py:45-51), reduced on the device */
+int gf_sampler_walker_mean(gf_sampler* s, double* mean);
 int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts);
 /* same, chain ch propagated with models[ch] (NULL: the sampling models): scripts/mc_texture.py samples the
  * priors (:148-170) and pushes every sample through flux_averaged_BSMu of the grid point (:216-221) */

@@ -178,6 +178,40 @@ def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
     f.close()
 
 
+def test_walker_mean_and_acor_on_device(golden):
+    """mcmc.py:45-51 prints sampler.acor: the ensemble-mean series is reduced on the device."""
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    rng = np.random.default_rng(5)
+    p0 = np.stack([uniform_theta(ps, 100, rng, seeds=True) for _ in range(2)])
+    s = mcmc_utils.DeviceEnsembleSampler(100, 6, f, nchains=2, seed=3)      # 100 walkers: 600 elements per step, 252-thread stride
+    s.run_mcmc(p0, 500, storechain=False)
+    s.reset()
+    s.run_mcmc(None, 3000, thin=1)
+    m = s.walker_mean()
+    ref = s.chain.mean(axis=1)                                               # (2, 3000, 6)
+    assert m.shape == (2, 3000, 6)
+    assert np.abs(m - ref).max() < 1e-13
+    with pytest.raises(mcmc_utils.AutocorrError):                           # 3000 steps < 50 tau: emcee-2 refuses too
+        s.acor
+    tau = s.get_autocorr_time(tol=10)
+    assert tau.shape == (2, 6) and np.all(np.isfinite(tau)) and np.all(tau > 20) and np.all(tau < 300)   # notebook: 85-125
+    assert np.allclose(tau[0], mcmc_utils.integrated_time(ref[0], tol=10), rtol=1e-9)
+    s.close()
+    # 4-dim, 64 walkers (256 elements per step: full-block stride), single chain
+    ps4 = Cf.unitary_paramset()
+    from golemflavor_amd.descriptor import compile_model
+    from golemflavor_amd.model import Model
+    m4 = Model(compile_model(ps4, "PRIOR_ONLY", source_ratio=(1, 2, 0)))
+    np.random.seed(2)
+    s4 = mcmc_utils.DeviceEnsembleSampler(64, 4, m4, seed=9)
+    s4.run_mcmc(mcmc_utils.flat_seed(ps4, 64), 37, thin=2)
+    assert np.abs(s4.walker_mean() - s4.chain.mean(axis=0)).max() < 1e-13
+    s4.close()
+    m4.close()
+    f.close()
+
+
 def test_device_sampler_bookkeeping_and_reset(golden):
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)
