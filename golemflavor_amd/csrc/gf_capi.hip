@@ -296,6 +296,17 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         if (!idx_ok(d->idx_mass[k]) || !idx_ok(d->idx_src[k])) return GF_ERR_INVALID_ARG;
     if (!idx_ok(d->idx_scale) || !idx_ok(d->idx_gamma)) return GF_ERR_INVALID_ARG;
     if ((d->idx_src[0] < 0) != (d->idx_src[1] < 0)) return GF_ERR_INVALID_ARG;
+    // CP phases (dcp, and the NP matrix's for texture NONE): the kernels' sine / cosine reduce |x| < GF_PHASE_MAX
+    // only (every paramset of the reference boxes them into [0, 2 pi]: scripts/fr.py:41, mc_unitary.py:39)
+    auto phase_ok = [&](int idx, double fixed) {
+        if (idx >= 0) return std::fabs(d->lo[idx]) <= GF_PHASE_MAX && std::fabs(d->hi[idx]) <= GF_PHASE_MAX;
+        return std::fabs(fixed) <= GF_PHASE_MAX;
+    };
+    if (!phase_ok(d->idx_sm[3], d->sm_fixed[3]) ||
+        (d->mode == GF_MODE_BSM_GAUSS && d->texture == GF_TEX_NONE && !phase_ok(d->idx_mm[3], d->mm_fixed[3]))) {
+        std::snprintf(g_err, sizeof(g_err), "CP phase range or value beyond +-%g is not supported", GF_PHASE_MAX);
+        return GF_ERR_UNSUPPORTED;
+    }
 
     gf_model* m = new (std::nothrow) gf_model();
     if (!m) return GF_ERR_ALLOC;

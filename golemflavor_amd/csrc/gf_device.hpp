@@ -60,10 +60,13 @@ static __device__ __attribute__((noinline)) void sincos_cold(double x, double* s
 
 // sin and cos of x, |x| < 2^20 * pi/2: three-step Cody-Waite reduction with FMA (33-bit pieces of pi/2,
 // the published fdlibm split), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error
-// <= ~2e-16.  Larger |x| (never a physical phase) take the library path.
+// <= ~2e-16.  Larger |x| (never a physical phase) give NaN.
 __device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs)
 {
-    if (!(fabs(x) < 1.6e6)) { *sn = gf_nan(); *cs = gf_nan(); return; }   // TEMP
+    // beyond the reduction's range (never a physical phase): NaN -> GF_ST_NAN.  gf_model_create refuses models
+    // whose phase columns could get here (GF_PHASE_MAX), so that the library's Payne-Hanek path -- ~100 VGPRs and
+    // a scratch frame for every kernel that can reach it -- stays out of the hot kernels' register budget.
+    if (!(fabs(x) < 1.6e6)) { *sn = gf_nan(); *cs = gf_nan(); return; }
     const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
     double r = fma(-fn, 1.57079632673412561417e+00, x);              // pio2_1 (33 bits)
     r = fma(-fn, 6.07710050630396597660e-11, r);                     // pio2_2 (33 bits)

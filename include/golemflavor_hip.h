@@ -29,6 +29,10 @@ extern "C" {
 #define GF_ABI_VERSION 1
 #define GF_MAX_DIM 16
 #define GF_MAX_BINS 64
+/* CP phases (dcp; the NP matrix's for texture NONE) must stay within +-GF_PHASE_MAX: range (sampled) or value
+ * (fixed).  The reference's paramsets box them into [0, 2 pi] (scripts/fr.py:41, scripts/mc_unitary.py:39);
+ * gf_model_create returns GF_ERR_UNSUPPORTED otherwise. */
+#define GF_PHASE_MAX 1.0e6
 
 typedef enum gf_error {
     GF_OK = 0,

@@ -416,6 +416,41 @@ def test_max_bins_64(oracle):
 
 
 # ---------------------------------------------------------------- every specialisation of the fast SM kernel
+def test_cp_phase_outside_zero_two_pi(golden, oracle):
+    """The fast cosine folds [0, 2 pi]; a paramset that boxes dcp elsewhere (here [-pi, 3 pi]) takes the general
+    Cody-Waite path and must agree with the oracle just the same; C-ABI argument checks on the way."""
+    asimov, ps0 = notebook_sets(golden)
+    params = []
+    for p in ps0:
+        if p.name == "dcp":
+            params.append(Param(name="dcp", value=p.value, ranges=[-np.pi, 3 * np.pi], std=p.std, tag=p.tag, tex=p.tex))
+        else:
+            params.append(p)
+    ps = ParamSet(params)
+    bf = golden["g6_bestfit_fr"]
+    m = Model(compile_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02))
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02)
+    rng = np.random.default_rng(17)
+    th = uniform_theta(ps, 64 * 50 + 13, rng, seeds=False)
+    th[:, 3] = rng.uniform(-np.pi, 3 * np.pi, len(th))
+    got, st = m.lnprob(th)
+    ref, rst = oracle.lnprob_batch(om, th, want_status=True)
+    assert np.array_equal(st, rst)
+    fin = np.isfinite(ref)
+    assert fin.sum() > 100 and np.array_equal(np.isfinite(got), fin)
+    assert rel_err(got[fin], ref[fin]) < REL
+    # device entry points check their pointers: NULL and misaligned theta are refused, not dereferenced
+    L = _lib.lib()
+    d_th = m.alloc(th.nbytes).upload(th)
+    d_out = m.alloc(8 * len(th))
+    assert L.gf_lnprob_batch_device(m._h, None, GF_LAYOUT_AOS, 10, d_out.ptr, None, None) == _lib.GF_ERR_INVALID_ARG
+    assert L.gf_lnprob_batch_device(m._h, d_th.at(8), GF_LAYOUT_AOS, 10, d_out.ptr, None, None) == _lib.GF_ERR_INVALID_ARG
+    assert L.gf_lnprob_batch_device(m._h, d_th.ptr, 7, 10, d_out.ptr, None, None) == _lib.GF_ERR_INVALID_ARG
+    assert L.gf_lnprob_batch_device(m._h, d_th.ptr, GF_LAYOUT_AOS, 0, d_out.ptr, None, None) == _lib.GF_OK
+    assert L.gf_lnprob_batch(None, None, 1, None, None, None) == _lib.GF_ERR_INVALID_ARG
+    m.close()
+
+
 @pytest.mark.parametrize("case", ["permuted6", "fixed_source4", "odd7", "wide12"])
 def test_fast_kernel_specialisations(oracle, case):
     """k_lnprob_sm_fast is instantiated per (ndim, sampled/canonical, fr): cover the non-canonical column

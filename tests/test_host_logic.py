@@ -139,6 +139,11 @@ def test_model_create_validates_before_touching_the_device(golden):
     d.sigma[0] = -1.0
     assert L.gf_model_create(C.byref(d), 0, C.byref(h)) == _lib.GF_ERR_INVALID_ARG
     d.sigma[0] = 0.013
+    # CP phase range beyond the kernels' argument reduction: refused, not silently NaN
+    d.hi[3] = 4.0e6
+    assert L.gf_model_create(C.byref(d), 0, C.byref(h)) == _lib.GF_ERR_UNSUPPORTED
+    assert b"phase" in L.gf_last_hip_error()
+    d.hi[3] = 2 * np.pi
     if _lib.device_count() == 0:
         # no GPU in this container: the product path fails loudly, there is no CPU fallback
         rc = L.gf_model_create(C.byref(d), 0, C.byref(h))
