@@ -135,6 +135,36 @@ class RcclBackend:
             self._h = None
 
 
+def open_rccl(rank, world, device, timeout=120.0):
+    """An RcclBackend whose bootstrap cannot hang the job: the communicator is created in a helper thread
+    with a bounded wait, and (world > 1) all ranks agree over torch.distributed whether everybody got one.
+    Returns (backend or None, error string or None)."""
+    import threading
+    box = {}
+
+    def _setup():
+        try:
+            box["b"] = RcclBackend(rank, world, device)
+        except Exception as exc:           # noqa: BLE001
+            box["err"] = "%s: %s" % (type(exc).__name__, exc)
+
+    th = threading.Thread(target=_setup, daemon=True)
+    th.start()
+    th.join(timeout=timeout)
+    err = "timeout: RCCL communicator setup did not finish" if th.is_alive() else box.get("err")
+    if world > 1:
+        import torch.distributed as tdist
+        errs = [None] * world
+        tdist.all_gather_object(errs, err)
+        err = next((e for e in errs if e is not None), None)
+    if err is not None:
+        b = box.get("b")
+        if b is not None:
+            b.close()
+        return None, err
+    return box["b"], None
+
+
 def broadcast_descriptors(descs, backend, root=0):
     """Rank `root`'s packed gf_model_desc list -> every rank (the 'fixed physics constants')."""
     from ._lib import GfModelDesc

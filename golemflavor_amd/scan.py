@@ -196,7 +196,18 @@ def main(argv=None):
     mine = gdist.shard(len(pts), backend.rank, backend.world)
     local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=not a.no_stack)
     t1 = time.perf_counter()
-    chains = gdist.gather_chains(local, len(pts), backend)
+    # chain blocks travel over RCCL / xGMI (device all-gather through the library's own communicator); gloo is
+    # the fallback when the communicator cannot be set up, and the control plane either way
+    rccl, rccl_err, allgather = None, None, None
+    if world > 1 or os.environ.get("GF_SCAN_RCCL"):
+        rccl, rccl_err = gdist.open_rccl(rank, world, device, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "120")))
+    if rccl is not None:
+        stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
+        allgather = lambda arr: rccl.allgather(arr, stage)  # noqa: E731
+    chains = gdist.gather_chains(local, len(pts), backend, allgather=allgather)
+    if rccl is not None:
+        stage.close()
+        rccl.close()
     PHASES["gather"] = time.perf_counter() - t1
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -204,6 +215,7 @@ def main(argv=None):
             mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
                           "nsteps": a.nsteps, "stacked": not a.no_stack,
+                          "gather": "rccl" if rccl is not None else ("gloo" if world > 1 else "local"), "rccl_error": rccl_err,
                           "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,
                           "phases": {k: round(v, 4) for k, v in PHASES.items()},
                           "evals_per_s": len(pts) * evals_per_point / dt,

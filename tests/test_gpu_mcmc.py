@@ -97,4 +97,20 @@ def test_grid_scans_c4_c5_smoke(capsys):
     assert out["chains_shape"] == [3, 32 * 15, 9] and out["finite_fraction"] > 0.9
     scan.main(["--config", "C5", "--points", "2", "--nwalkers", "32", "--burnin", "5", "--nsteps", "10"])
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0
+    assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0 and out["gather"] == "local"
+
+
+def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
+    """The chain gather of a scan through the library's RCCL communicator (one rank here; the same code path
+    all-gathers over xGMI on N ranks): result identical to the local gather."""
+    import json
+    from golemflavor_amd import scan
+    args = ["--config", "C4", "--points", "3", "--nwalkers", "32", "--burnin", "10", "--nsteps", "15"]
+    scan.main(args + ["--outfile", str(tmp_path / "local")])
+    capsys.readouterr()
+    monkeypatch.setenv("GF_SCAN_RCCL", "1")
+    scan.main(args + ["--outfile", str(tmp_path / "rccl")])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["gather"] == "rccl" and out["rccl_error"] is None
+    a, b = np.load(str(tmp_path / "local.npy")), np.load(str(tmp_path / "rccl.npy"))
+    assert a.shape == (3, 32 * 15, 9) and np.array_equal(a, b, equal_nan=True)
