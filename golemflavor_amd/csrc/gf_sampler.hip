@@ -260,6 +260,145 @@ hipError_t launch_stretch_nml(const GfCommon& c, const GfBsm* tb, const double* 
     return hipGetLastError();
 }
 
+// ---- one workgroup per ensemble, a whole run in ONE launch --------------------------------------------
+// An ensemble of up to a few thousand walkers is a few waves of work per half-step: launched as a grid, every
+// half-step is a ~3 us launch that the GPU spends mostly idle (the emcee regime: 100-walker chains, C1).  Here
+// block b owns ensemble b for the whole run: walkers, their lnprob and acceptance counters live in LDS, the two
+// half-steps of a step are separated by a workgroup barrier instead of a kernel boundary, and the only HBM
+// traffic is the stored chain.  Random stream, proposal, evaluation and accept rule are those of k_stretch, so
+// the chain is bitwise the same (tests compare the two).  PRIOR_ONLY and SM_GAUSS posteriors.
+struct PersistArgs {
+    const GfCommon* commons;        // [nmodels]
+    const double* const* ptabs;     // [nmodels]
+    int32_t nmodels;                // 1: every chain samples commons[0]; else one per chain
+    int32_t nwalkers;
+    double* pos;                    // [nchains][nwalkers][ndim]
+    double* lnp;                    // [nchains][nwalkers]
+    uint32_t* naccept;              // [nchains][nwalkers]
+    double* chain;                  // [nchains][nstore_cap][nwalkers][ndim] or null
+    double* lnp_chain;
+    int64_t nstore_cap, store_base;
+    uint64_t seed, iteration_base;
+    int64_t nsteps;
+    int32_t thin, store;
+    double a;
+};
+
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(1024) void k_stretch_persist(const PersistArgs s)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int chain = blockIdx.x;
+    const GfCommon& c = s.commons[s.nmodels > 1 ? chain : 0];
+    const double* __restrict__ ptab = s.ptabs[s.nmodels > 1 ? chain : 0];
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int nw = s.nwalkers, nhalf = nw / 2, nt = blockDim.x;
+    // LDS: ctab[64] | pos[nw][ndim] | lnp[nw] | rows[nt][ndim] | naccept[nw] (u32)
+    double* ctab = dyn;
+    double* pos = ctab + GF_MAX_DIM * 4;
+    double* lnp = pos + (size_t)nw * ndim;
+    double* rows = lnp + nw;
+    uint32_t* nacc = reinterpret_cast<uint32_t*>(rows + (size_t)nt * ndim);
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    const int64_t cw = (int64_t)chain * nw;
+    for (int i = threadIdx.x; i < nw * ndim; i += nt) pos[i] = s.pos[cw * ndim + i];
+    for (int i = threadIdx.x; i < nw; i += nt) { lnp[i] = s.lnp[cw + i]; nacc[i] = s.naccept[cw + i]; }
+    __syncthreads();
+    double* row = rows + (size_t)threadIdx.x * ndim;
+    const uint32_t k0 = (uint32_t)s.seed, k1 = (uint32_t)(s.seed >> 32);
+
+    for (int64_t step = 0; step < s.nsteps; ++step) {
+        const uint64_t iteration = s.iteration_base + (uint64_t)step;
+        const bool store_now = s.store != 0 && s.chain != nullptr && (step % s.thin) == 0;
+        const int64_t store_index = s.store_base + (step + s.thin - 1) / s.thin;
+        for (int half = 0; half < 2; ++half) {
+            const int cbase = (1 - half) * nhalf;
+            const uint64_t ctr = 2 * iteration + half;
+            for (int k = threadIdx.x; k < nhalf; k += nt) {
+                const int64_t g = (int64_t)chain * nhalf + k;
+                const int w = half * nhalf + k;
+                uint32_t r[4];
+                philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r);
+                const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+                const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
+                const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+                const double zr = fma(s.a - 1.0, u1, 1.0);
+                const double z = zr * zr / s.a;
+                double* sk = pos + (size_t)w * ndim;
+                const double* cj = pos + (size_t)(cbase + j) * ndim;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (!NDIM && d >= ndim) break;
+                    const double cv = cj[d];
+                    row[d] = fma(-z, cv - sk[d], cv);
+                }
+                int st;
+                const double lnq = proposal_lnprob<NDIM, MODE, 1>(c, nullptr, ctab, nullptr, row, ndim, st, 0, nullptr);
+                const double lnk = lnp[w];
+                double zp = 1.0;
+                for (int d = 1; d < ndim; ++d) zp *= z;
+                const double lhs = log(zp / u3);
+                const bool accept = lhs > lnk - lnq;
+                if (accept) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        if (!NDIM && d >= ndim) break;
+                        sk[d] = row[d];
+                    }
+                    lnp[w] = lnq;
+                    nacc[w] += 1u;
+                }
+                if (store_now) {
+                    double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * nw + w) * ndim;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        if (!NDIM && d >= ndim) break;
+                        dst[d] = sk[d];                           // the walker's position after this half-step
+                    }
+                    if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = lnp[w];
+                }
+            }
+            __syncthreads();                                      // the other half moves next: it reads these walkers
+        }
+    }
+    for (int i = threadIdx.x; i < nw * ndim; i += nt) s.pos[cw * ndim + i] = pos[i];
+    for (int i = threadIdx.x; i < nw; i += nt) { s.lnp[cw + i] = lnp[i]; s.naccept[cw + i] = nacc[i]; }
+}
+
+// threads and dynamic LDS of the persistent kernel; lds == 0: the ensemble does not fit one workgroup
+inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds)
+{
+    const int nhalf = nwalkers / 2;
+    int nt = ((nhalf + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
+    if (nt > 1024) nt = 1024;
+    const size_t bytes = sizeof(double) * ((size_t)GF_MAX_DIM * 4 + (size_t)nwalkers * ndim + nwalkers + (size_t)nt * ndim) +
+                         sizeof(uint32_t) * (size_t)nwalkers;
+    *threads = nt;
+    *lds = (bytes <= 64 * 1024 && nhalf <= 4 * 1024) ? bytes : 0;
+}
+
+template <int NDIM>
+hipError_t launch_persist_n(int mode, int nchains, int threads, size_t lds, const PersistArgs& a, hipStream_t st)
+{
+    if (mode == MODE_PRIOR_ONLY)
+        hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY>), dim3(nchains), dim3(threads), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS>), dim3(nchains), dim3(threads), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_persist(int mode, int ndim, int nchains, int threads, size_t lds, const PersistArgs& a, hipStream_t st)
+{
+    switch (ndim) {
+    case 4: return launch_persist_n<4>(mode, nchains, threads, lds, a, st);
+    case 6: return launch_persist_n<6>(mode, nchains, threads, lds, a, st);
+    case 7: return launch_persist_n<7>(mode, nchains, threads, lds, a, st);
+    case 12: return launch_persist_n<12>(mode, nchains, threads, lds, a, st);
+    default: return launch_persist_n<0>(mode, nchains, threads, lds, a, st);
+    }
+}
+
 // Ensemble mean of every stored step: chain [nchains][cap][nwalkers][ndim] -> mean [nchains][nstored][ndim]
 // (the series emcee's acor works on, golemflavor/mcmc.py:45-51).  One block per (step, chain); thread t sums
 // the elements t, t + 256, ... of the step's contiguous nwalkers x ndim block whose column is (t mod ndim)
@@ -395,6 +534,11 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
     if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(StepState));
     if (e == hipSuccess) e = hipMemset(s->d_naccept, 0, sizeof(uint32_t) * nw);
     if (e == hipSuccess) e = hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4);
+    // device copies of the constants for the kernels that take them by pointer (k_stretch_persist)
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*));
+    if (e == hipSuccess) e = hipMemcpy(s->d_commons, c, sizeof(GfCommon), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)s->d_ptabs, &ptab, sizeof(void*), hipMemcpyHostToDevice);
     if (e != hipSuccess) { int rc = sfail(e, "gf_sampler_create"); gf_sampler_destroy(s); return rc; }
     *out = s;
     return GF_OK;
@@ -458,6 +602,8 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
     if (rc != GF_OK) { cleanup(); delete[] keep; return rc; }
     s->models = keep;
     s->nbins_max = nbins_max;
+    (void)hipFree(s->d_commons); s->d_commons = nullptr;            // the one-entry tables of gf_sampler_create
+    (void)hipFree((void*)s->d_ptabs); s->d_ptabs = nullptr;
     hipError_t e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_tbs, sizeof(void*) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*) * nchains);
@@ -554,7 +700,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     a.chain = store ? s->d_chain : nullptr;
     a.lnp_chain = store ? s->d_lnp_chain : nullptr;
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
-    a.commons = s->d_commons; a.tbs = s->d_tbs; a.ptabs = s->d_ptabs;
+    a.commons = s->models ? s->d_commons : nullptr; a.tbs = s->d_tbs; a.ptabs = s->d_ptabs;
     a.nbins_max = s->nbins_max;
     a.lpw = lanes_per_walker(c->mode, (int64_t)s->nchains * (s->nwalkers / 2), s->nbins_max, s->cus);
     auto steps = [&](int count) -> hipError_t {       // `count` steps relative to the current base, then tick
@@ -569,6 +715,37 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, s->d_state, count);
         return hipGetLastError();
     };
+    // small ensembles of a PRIOR_ONLY / SM_GAUSS posterior: one workgroup per ensemble, the whole run in one launch
+    {
+        int threads = 0;
+        size_t lds = 0;
+        persist_geometry(s->nwalkers, s->ndim, &threads, &lds);
+        const char* env = std::getenv("GF_SAMPLER_PERSIST");          // "0": always the per-half-step grid kernels
+        if (c->mode != MODE_BSM_GAUSS && lds > 0 && !(env && env[0] == '0')) {
+            PersistArgs pa;
+            pa.commons = s->d_commons; pa.ptabs = s->d_ptabs; pa.nmodels = s->models ? s->nchains : 1;
+            pa.nwalkers = s->nwalkers; pa.pos = s->d_pos; pa.lnp = s->d_lnp; pa.naccept = s->d_naccept;
+            pa.chain = store ? s->d_chain : nullptr; pa.lnp_chain = store ? s->d_lnp_chain : nullptr;
+            pa.nstore_cap = s->nstore_cap; pa.seed = s->seed; pa.thin = thin; pa.store = store ? 1 : 0; pa.a = s->a;
+            constexpr int64_t CHUNK = 1 << 16;                          // steps per launch (multiple of any thin <= 2^16? no: see below)
+            int64_t done_p = 0;
+            while (done_p < nsteps) {
+                // a chunk boundary must fall on a stored step so that (step % thin) restarts at 0: whole multiples of thin
+                int64_t count = nsteps - done_p < CHUNK ? nsteps - done_p : CHUNK;
+                if (count < nsteps - done_p && thin > 1) count = (count / thin) * thin ? (count / thin) * thin : thin;
+                pa.iteration_base = s->iteration + (uint64_t)done_p;
+                pa.store_base = s->nstored + (done_p + thin - 1) / thin;
+                pa.nsteps = count;
+                hipError_t e = launch_persist(c->mode, s->ndim, s->nchains, threads, lds, pa, st);
+                if (e != hipSuccess) return sfail(e, "persistent stretch launch");
+                done_p += count;
+            }
+            s->iteration += (uint64_t)nsteps;
+            s->steps_since_reset += nsteps;
+            if (store) s->nstored += (nsteps + thin - 1) / thin;
+            return GF_OK;
+        }
+    }
     constexpr int GRAPH_STEPS = 16;
     int64_t done = 0;
     static const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;   // diagnostics

@@ -212,6 +212,33 @@ def test_walker_mean_and_acor_on_device(golden):
     f.close()
 
 
+@pytest.mark.parametrize("nwalkers,thin", [(100, 1), (36, 3), (640, 2)])
+def test_persistent_workgroup_sampler_equals_grid_sampler(golden, monkeypatch, nwalkers, thin):
+    """Small ensembles run one workgroup per ensemble with the walkers in LDS and the whole run in one launch;
+    same random stream and arithmetic as the per-half-step grid kernels -> bitwise the same chain."""
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    rng = np.random.default_rng(nwalkers)
+    nchains = 3
+    p0 = np.stack([uniform_theta(ps, nwalkers, rng, seeds=True) for _ in range(nchains)])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GF_SAMPLER_PERSIST", mode)
+        s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=1234)
+        s.run_mcmc(p0, 21, storechain=False)
+        s.reset()
+        s.run_mcmc(None, 40, thin=thin)
+        s.run_mcmc(None, 2 * thin, thin=thin)                    # a second stored run appends
+        out[mode] = (s.chain, s.lnprobability, s.acceptance_fraction, s.state[0], s.state[1])
+        assert s.chain.shape == (nchains, nwalkers, (40 + thin - 1) // thin + 2, 6)
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_PERSIST")
+    for x, y in zip(out["1"], out["0"]):
+        assert np.array_equal(x, y)
+    assert 0.2 < out["1"][2].mean() < 0.7
+    f.close()
+
+
 def test_device_sampler_bookkeeping_and_reset(golden):
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)

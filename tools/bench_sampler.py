@@ -12,7 +12,9 @@ def main():
     ang = fr_utils.fr_to_angles(fr_utils.u_to_fr((1, 0, 0), fr_utils.NUFIT_U))
     asimov, ps = Cf.notebook_paramsets(ang)
     f = llh_utils.notebook_ln_prob(asimov, ps)
-    for nwalkers, nchains, nsteps in ((100, 1, 2000), (4096, 1, 2000), (4096, 16, 1000), (4096, 64, 400), (4096, 256, 200), (2048, 64, 500)):
+    cases = ((100, 1, 20000), (100, 256, 5000), (512, 1, 10000), (512, 256, 2000), (512, 2048, 500),
+             (4096, 1, 2000), (4096, 16, 1000), (4096, 64, 400), (4096, 256, 200), (2048, 64, 500))
+    for nwalkers, nchains, nsteps in cases:
         np.random.seed(26)
         p0 = np.stack([mcmc_utils.flat_seed(ps, nwalkers) for _ in range(nchains)])
         s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 6, f, nchains=nchains, seed=1)
@@ -21,7 +23,7 @@ def main():
         s.run_mcmc(None, nsteps, storechain=False)
         dt = time.perf_counter() - t0
         acc = float(np.mean(s.acceptance_fraction))
-        print(json.dumps({"sampler": "device", "nwalkers": nwalkers, "nchains": nchains, "steps": nsteps,
+        print(json.dumps({"sampler": "device", "persist": os.environ.get("GF_SAMPLER_PERSIST", "auto"), "nwalkers": nwalkers, "nchains": nchains, "steps": nsteps,
                           "us_per_step": 1e6 * dt / nsteps, "evals_per_s": nwalkers * nchains * nsteps / dt, "acceptance": acc}))
         s.close()
     for nwalkers, nsteps in ((100, 500), (4096, 300)):
