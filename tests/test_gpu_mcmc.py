@@ -114,3 +114,29 @@ def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
     assert out["gather"] == "rccl" and out["rccl_error"] is None
     a, b = np.load(str(tmp_path / "local.npy")), np.load(str(tmp_path / "rccl.npy"))
     assert a.shape == (3, 32 * 15, 9) and np.array_equal(a, b, equal_nan=True)
+
+
+def test_integration_md_stub_is_executable(golden, oracle):
+    """INTEGRATION.md section 2 is the ctypes stub a GolemFlavor maintainer would add.  Run exactly that text
+    (with this package's Param/enums/fr standing in for the reference's, same names and values) against the oracle."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# golemflavor/hip.py.*?)```", text, re.S).group(1)
+    code = code.replace("from golemflavor.", "from golemflavor_amd.").replace("from golemflavor import", "from golemflavor_amd import")
+    code = code.replace('C.CDLL("libgolemhip.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    asimov, ps = notebook_sets(golden)
+    f = ns["HipLnProb"](asimov, ps)
+    th = np.ascontiguousarray(golden["g6_theta"][:512])
+    got = f(th)
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=golden["g6_bestfit_fr"], smearing=0.02)
+    ref = oracle.lnprob_batch(om, th)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.abs(got[fin] - ref[fin]).max() <= 1e-10 * np.abs(ref[fin]).max()
+    assert isinstance(f(th[0]), float) and f(th[0]) == got[0]
+    with pytest.raises(AssertionError):
+        f(np.zeros(5))
