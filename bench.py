@@ -213,8 +213,9 @@ def main():
     for _ in range(a.steps):
         step()
     ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
+    model.sync()                                       # this rank's K steps are complete ...
+    elapsed = time.perf_counter() - t0                 # ... at this instant; the MAX over ranks below is the job's time
+    fence()                                            # closing bracket: barrier + synchronize (its latency is not a step)
     kernel_ms = ev0.elapsed_ms(ev1) / a.steps          # average launch duration on the kernel's stream
 
     if dist is not None:

@@ -572,7 +572,7 @@ void gf_sampler_destroy(gf_sampler* s)
 // smearing, texture, dimension, binning -- may differ.  The models must outlive the sampler.
 int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out)
 {
-    if (!models || !out || nchains < 1) return GF_ERR_INVALID_ARG;
+    if (!models || !out || nchains < 1 || nchains > 65535) return GF_ERR_INVALID_ARG;   // blockIdx.y = chain
     *out = nullptr;
     for (int ch = 0; ch < nchains; ++ch)
         if (!models[ch]) return GF_ERR_INVALID_ARG;
@@ -843,9 +843,14 @@ int gf_sampler_walker_mean(gf_sampler* s, double* mean)
     const size_t bytes = sizeof(double) * (size_t)s->nchains * s->nstored * s->ndim;
     double* d_mean = nullptr;
     GFS_HIP(hipMalloc((void**)&d_mean, bytes));
-    hipLaunchKernelGGL(k_walker_mean, dim3((unsigned)s->nstored, (unsigned)s->nchains), dim3(GF_BLOCK), 0, st, s->d_chain,
-                       s->nstore_cap, s->nstored, s->nwalkers, s->ndim, d_mean);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipSuccess;
+    for (int ch0 = 0; ch0 < s->nchains && e == hipSuccess; ch0 += 65535) {          // gridDim.y <= 65535
+        const int nch = s->nchains - ch0 < 65535 ? s->nchains - ch0 : 65535;
+        hipLaunchKernelGGL(k_walker_mean, dim3((unsigned)s->nstored, (unsigned)nch), dim3(GF_BLOCK), 0, st,
+                           s->d_chain + (size_t)ch0 * s->nstore_cap * s->nwalkers * s->ndim, s->nstore_cap, s->nstored, s->nwalkers,
+                           s->ndim, d_mean + (size_t)ch0 * s->nstored * s->ndim);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(mean, d_mean, bytes, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_mean);
