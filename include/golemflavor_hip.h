@@ -175,7 +175,10 @@ int gf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);  /* synchroni
 /* The emcee step either side of the path (golemflavor/mcmc.py:29-49: EnsembleSampler.sample / reset /
  * chain / acceptance_fraction), run entirely on the device: `nchains` independent ensembles of `nwalkers`
  * walkers of the model's posterior, affine-invariant stretch move (scale `a`, emcee's default 2.0),
- * Philox4x32-10 keyed by `seed`.  One launch per half-ensemble update; the host sees chains at the end. */
+ * Philox4x32-10 keyed by `seed`; the host sees chains at the end.  Launch shape is chosen per run and does not
+ * change the chain: one launch per half-ensemble update (hipGraph replay), or -- small PRIOR_ONLY / SM_GAUSS
+ * ensembles -- one workgroup per ensemble with the walkers in LDS and the whole run in one launch; small BSM
+ * ensembles split a walker's energy bins over 4 or 16 lanes. */
 typedef struct gf_sampler gf_sampler;
 int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out);
 /* One ensemble per model (grid scans: submitter/sens_dag.py:75-95 and mc_texture_dag.py:57-71 run one job per
@@ -196,13 +199,13 @@ int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob);
 /* chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
  * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on; NULL = skip */
 int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary);
+/* mean [nchains][nstored][ndim]: ensemble mean of every stored step, the series behind sampler.acor
+ * (golemflavor/mcmc.py:45-51), reduced on the device */
+int gf_sampler_walker_mean(gf_sampler* s, double* mean);
 /* Chain post-processing on the device (scripts/mc_unitary.py:189-193, scripts/mc_texture.py:216-221,
  * golemflavor/plot.py:365-370): composition of every stored sample and/or its [nbins]^3 histogram per
  * chain.  fr [nchains][nstored][nwalkers][3], status [nchains][nstored][nwalkers],
  * counts [nchains][nbins]^3; NULL = skip. */
-/* mean [nchains][nstored][ndim]: ensemble mean of every stored step, the series behind sampler.acor
- * (golemflavor/mcmc.py:45-51), reduced on the device */
-int gf_sampler_walker_mean(gf_sampler* s, double* mean);
 int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins, uint64_t* counts);
 /* same, chain ch propagated with models[ch] (NULL: the sampling models): scripts/mc_texture.py samples the
  * priors (:148-170) and pushes every sample through flux_averaged_BSMu of the grid point (:216-221) */
