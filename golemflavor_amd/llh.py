@@ -16,7 +16,8 @@ from .descriptor import compile_model
 from .enums import ParamTag, Texture
 from .model import Model
 
-__all__ = ["LnProb", "CubeLnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior"]
+__all__ = ["LnProb", "CubeLnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior",
+           "ln_prob", "triangle_llh", "multi_gaussian"]
 
 
 class LnProb:
@@ -87,6 +88,67 @@ def lnprior(theta, paramset, device=0):
         return f(theta)
     finally:
         f.close()
+
+
+# ---- the reference's own function names and signatures -------------------------------------------------
+# `partial(ln_prob, args=args, asimov_paramset=..., llh_paramset=...)` (scripts/fr.py:182-187) keeps working:
+# the bound state is compiled into a device model the first time it is seen and looked up afterwards.
+_BOUND = {}
+_BOUND_MAX = 64
+
+
+def _fingerprint(args, asimov_paramset, llh_paramset, smearing):
+    """Everything of the bound state the posterior depends on (param *values* are overwritten by theta in the
+    reference, llh.py:72-73, so they are not part of it -- except for columns the model keeps fixed)."""
+    ps = tuple((p.name, float(p.ranges[0]), float(p.ranges[1]), p.prior.value, float(p.nominal_value),
+                None if p.std is None else float(p.std), p.tag.value if hasattr(p.tag, "value") else str(p.tag))
+               for p in llh_paramset)
+    bf = tuple(float(x) for x in asimov_paramset.from_tag(ParamTag.BESTFIT, values=True))
+    tex = args.texture.value if hasattr(args.texture, "value") else int(args.texture)
+    return (ps, bf, tuple(float(x) for x in np.ravel(args.source_ratio)), int(args.dimension), tex,
+            tuple(float(x) for x in np.ravel(args.binning)), float(smearing))
+
+
+def _bound(args, asimov_paramset, llh_paramset):
+    smearing = float(getattr(args, "smearing", 0.02))
+    key = _fingerprint(args, asimov_paramset, llh_paramset, smearing)
+    f = _BOUND.get(key)
+    if f is None:
+        if len(_BOUND) >= _BOUND_MAX:                      # oldest first
+            _BOUND.pop(next(iter(_BOUND))).close()
+        f = _BOUND[key] = bsm_ln_prob(args, asimov_paramset, llh_paramset, smearing=smearing,
+                                      device=int(getattr(args, "device", 0)))
+    return f
+
+
+def multi_gaussian(fr, fr_bf, smearing, offset=-320):
+    """golemflavor/llh.py:32-54: log(multivariate_normal.pdf(fr, mean=fr_bf, cov=smearing^2 I)) + offset, with
+    the reference's underflow to -inf (the pdf is formed in fp64 before the log).  Host closed form for single
+    compositions; ensembles go through the model's kernel."""
+    d = (np.asarray(fr, dtype=np.float64) - np.asarray(fr_bf, dtype=np.float64)) * np.sqrt(1.0 / (smearing * smearing))
+    logpdf = -0.5 * (3 * np.log(2 * np.pi) + 3 * np.log(smearing * smearing) + np.sum(d * d, axis=-1))
+    with np.errstate(divide="ignore", under="ignore"):
+        return np.log(np.exp(logpdf)) + offset
+
+
+def triangle_llh(theta, args, asimov_paramset, llh_paramset):
+    """golemflavor/llh.py:94-119 with the Gaussian substitute for gf.get_llh (README.md:70-74): the composition
+    comes from the device (flux_averaged_BSMu of theta), the Gaussian is applied to it."""
+    if np.shape(theta)[-1] != len(llh_paramset):
+        raise AssertionError('Length of MCMC scan is not the same as the input '
+                             'params\ntheta={0}\nparamset]{1}'.format(theta, llh_paramset))
+    f = _bound(args, asimov_paramset, llh_paramset)
+    frs, st = f.model.propagate(theta)
+    if np.any(st == _lib.GF_ST_NON_UNITARY):
+        raise AssertionError("Matrix is not unitary!")
+    bf = fr_utils.angles_to_fr(asimov_paramset.from_tag(ParamTag.BESTFIT, values=True))
+    out = multi_gaussian(frs, bf, float(getattr(args, "smearing", 0.02)))
+    return float(out[0]) if np.ndim(theta) == 1 else out
+
+
+def ln_prob(theta, args, asimov_paramset, llh_paramset):
+    """golemflavor/llh.py:121-130, same name and signature; theta (ndim,) -> float or (n, ndim) -> (n,)."""
+    return _bound(args, asimov_paramset, llh_paramset)(theta)
 
 
 class CubeLnProb:

@@ -10,6 +10,7 @@ from common import BIN_EDGES, notebook_sets
 from golemflavor_amd import _lib
 from golemflavor_amd import configs as Cf
 from golemflavor_amd import fr as fr_utils
+from golemflavor_amd import llh as llh_utils
 from golemflavor_amd import mcmc as mcmc_utils
 from golemflavor_amd.descriptor import compile_model, log_gauss_mass
 from golemflavor_amd.enums import ParamTag, PriorsCateg, Texture
@@ -264,3 +265,14 @@ def test_chain_identifier_matches_reference_naming():
     a.source_ratio = np.array([0.3, 0.7, 0.0])
     assert mcmc_utils.chain_identifier(a) == "_DIM6_sfr_0.30_0.70_0.00"
     assert mcmc_utils.solve_ratio([0., 1., 0.]) == "0_1_0" and mcmc_utils.solve_ratio([2., 4., 0.]) == "1_2_0"
+
+
+def test_host_multi_gaussian_matches_golden(golden):
+    """llh.multi_gaussian (host closed form, llh.py:32-54) on the G5 vectors: near the mode, far tail,
+    subnormal band, -inf wall."""
+    got = llh_utils.multi_gaussian(golden["g5_fr"], golden["g5_bf"], 0.02)
+    ref = golden["g5_llh"]
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+    assert np.isinf(ref).sum() > 10 and fin.sum() > 100
