@@ -673,15 +673,19 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             double *nc = nullptr, *nl = nullptr;
             GFS_HIP(hipStreamSynchronize(st));
             GFS_HIP(hipMalloc((void**)&nc, sizeof(double) * nw * s->ndim * cap));
-            GFS_HIP(hipMalloc((void**)&nl, sizeof(double) * nw * cap));
+            {
+                hipError_t e_ = hipMalloc((void**)&nl, sizeof(double) * nw * cap);
+                if (e_ != hipSuccess) { (void)hipFree(nc); return sfail(e_, "hipMalloc(lnprob chain)"); }
+            }
             if (s->nstored > 0) {
-                for (int ch = 0; ch < s->nchains; ++ch) {
-                    GFS_HIP(hipMemcpy(nc + (size_t)ch * cap * s->nwalkers * s->ndim,
-                                      s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim,
-                                      sizeof(double) * s->nstored * s->nwalkers * s->ndim, hipMemcpyDeviceToDevice));
-                    GFS_HIP(hipMemcpy(nl + (size_t)ch * cap * s->nwalkers, s->d_lnp_chain + (size_t)ch * s->nstore_cap * s->nwalkers,
-                                      sizeof(double) * s->nstored * s->nwalkers, hipMemcpyDeviceToDevice));
-                }
+                // every chain's stored prefix in one strided copy: row = chain, pitch = old / new chain stride
+                const size_t row = sizeof(double) * s->nwalkers * s->ndim, lrow = sizeof(double) * s->nwalkers;
+                hipError_t e_ = hipMemcpy2D(nc, row * cap, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
+                                            hipMemcpyDeviceToDevice);
+                if (e_ == hipSuccess)
+                    e_ = hipMemcpy2D(nl, lrow * cap, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored, s->nchains,
+                                     hipMemcpyDeviceToDevice);
+                if (e_ != hipSuccess) { (void)hipFree(nc); (void)hipFree(nl); return sfail(e_, "chain repack"); }
             }
             if (s->d_chain) (void)hipFree(s->d_chain);
             if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
@@ -817,13 +821,15 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
     int rc = gf_model_sync(s->model);
     if (rc != GF_OK) return rc;
     const size_t per = (size_t)s->nwalkers;
-    for (int ch = 0; ch < s->nchains && s->nstored > 0; ++ch) {
+    if (s->nstored > 0) {
+        // one strided copy per array: row = chain (stored prefix), device pitch = capacity stride
+        const size_t row = sizeof(double) * per * s->ndim, lrow = sizeof(double) * per;
         if (chain)
-            GFS_HIP(hipMemcpy(chain + (size_t)ch * s->nstored * per * s->ndim, s->d_chain + (size_t)ch * s->nstore_cap * per * s->ndim,
-                              sizeof(double) * s->nstored * per * s->ndim, hipMemcpyDeviceToHost));
+            GFS_HIP(hipMemcpy2D(chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
+                                hipMemcpyDeviceToHost));
         if (lnprob_chain)
-            GFS_HIP(hipMemcpy(lnprob_chain + (size_t)ch * s->nstored * per, s->d_lnp_chain + (size_t)ch * s->nstore_cap * per,
-                              sizeof(double) * s->nstored * per, hipMemcpyDeviceToHost));
+            GFS_HIP(hipMemcpy2D(lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored,
+                                s->nchains, hipMemcpyDeviceToHost));
     }
     if (naccepted) GFS_HIP(hipMemcpy(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost));
     if (nonunitary) GFS_HIP(hipMemcpy(nonunitary, s->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
