@@ -69,6 +69,23 @@ def _scale_param(dimension):
     return Param(name='logLam', value=float(np.mean(b)), ranges=b, std=3, tag=ParamTag.SCALE)
 
 
+def tutorial_paramsets(asimov_angles, smearing=0.02):
+    """(asimov_paramset, llh_paramset) of examples/tutorial.ipynb cell 30: the two measured flavor angles are
+    sampled directly, flat in their boxes."""
+    tag = ParamTag.BESTFIT
+    asimov = ParamSet([
+        Param(name='measured_angle1', value=asimov_angles[0], ranges=[0., 1.], std=smearing, tag=tag,
+              tex=r'\sin^4\phi_\oplus'),
+        Param(name='measured_angle2', value=asimov_angles[1], ranges=[-1., 1.], std=smearing, tag=tag,
+              tex=r'\cos(2\psi_\oplus)'),
+    ])
+    llh = ParamSet([
+        Param(name='measured_angle1', value=0, ranges=[0., 1.], tag=tag, tex=r'\sin^4\phi_\oplus'),
+        Param(name='measured_angle2', value=0, ranges=[-1., 1.], tag=tag, tex=r'\cos(2\psi_\oplus)'),
+    ])
+    return asimov, llh
+
+
 def notebook_paramsets(asimov_angles, smearing=0.02):
     """(asimov_paramset, llh_paramset) of examples/inference.ipynb cells 9 and 17.
 

@@ -44,7 +44,8 @@ def log_gauss_mass(a, b):
 
 def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=-320.0,
                   source_ratio=(1.0, 2.0, 0.0), texture=Texture.NONE, dimension=3, binning=None,
-                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=(0.0, 0.0, 0.0, 0.0)):
+                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=(0.0, 0.0, 0.0, 0.0),
+                  sm_fixed=None, src_columns=None):
     """Flatten a posterior definition into a `GfModelDesc`.
 
     llh_paramset : ParamSet whose order is the column order of theta.
@@ -53,6 +54,9 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     source_ratio : args.source_ratio, used as given when the source is not sampled
                    (the scripts normalise it first, scripts/fr.py:118).
     binning      : energy bin *edges* (args.binning after process_args, scripts/fr.py:122-124).
+    sm_fixed     : the four mixing parameters used when they are not sampled (default: NuFIT, fr.py:313);
+                   (0, 1, 0, 0) is the identity matrix, i.e. no oscillation (examples/tutorial.ipynb).
+    src_columns  : the two columns holding the source flavor angles when they are not tagged SRCANGLES.
     """
     params = list(llh_paramset)
     ndim = len(params)
@@ -96,13 +100,15 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
         mass_idx = [-1, -1]
     for k in range(4):
         d.idx_sm[k] = sm_idx[k]
-        d.sm_fixed[k] = NUFIT_ANGLES[k]
+        d.sm_fixed[k] = float(sm_fixed[k]) if sm_fixed is not None else NUFIT_ANGLES[k]
         d.mm_fixed[k] = float(mm_fixed[k])
     for k in range(2):
         d.idx_mass[k] = mass_idx[k]
         d.mass_fixed[k] = MASS_EIGENVALUES[k]
 
     src_idx = [i for i, p in enumerate(params) if p.tag is ParamTag.SRCANGLES]
+    if src_columns is not None:
+        src_idx = [int(x) for x in src_columns]
     if len(src_idx) == 2:
         d.idx_src[0], d.idx_src[1] = src_idx
     elif not src_idx:

@@ -16,7 +16,7 @@ from .descriptor import compile_model
 from .enums import ParamTag, Texture
 from .model import Model
 
-__all__ = ["LnProb", "CubeLnProb", "notebook_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior",
+__all__ = ["LnProb", "CubeLnProb", "notebook_ln_prob", "tutorial_ln_prob", "bsm_ln_prob", "prior_ln_prob", "lnprior",
            "ln_prob", "triangle_llh", "multi_gaussian"]
 
 
@@ -61,6 +61,17 @@ def notebook_ln_prob(asimov_paramset, llh_paramset, device=0):
     bestfit = asimov_paramset.from_tag(ParamTag.BESTFIT)
     bf = fr_utils.angles_to_fr(bestfit.values)                 # ipynb:330
     desc = compile_model(llh_paramset, "SM_GAUSS", bestfit_fr=bf, smearing=bestfit[0].std)
+    return LnProb(desc, device=device)
+
+
+def tutorial_ln_prob(asimov_paramset, llh_paramset, device=0):
+    """The posterior of examples/tutorial.ipynb (cells 33 and 35): flat box priors + multi_gaussian(
+    angles_to_fr(theta), angles_to_fr(asimov angles), smearing) -- the two flavor angles ARE theta and nothing
+    oscillates, which is the Gaussian-likelihood kernel with the identity for a mixing matrix."""
+    bestfit = asimov_paramset.from_tag(ParamTag.BESTFIT)
+    bf = fr_utils.angles_to_fr(bestfit.values)
+    desc = compile_model(llh_paramset, "SM_GAUSS", bestfit_fr=bf, smearing=bestfit[0].std,
+                         sm_fixed=(0.0, 1.0, 0.0, 0.0), src_columns=(0, 1))
     return LnProb(desc, device=device)
 
 

@@ -166,7 +166,7 @@ def _name(e):
 
 def make_model(paramset, mode, *, bestfit_fr=(1 / 3, 1 / 3, 1 / 3), smearing=0.02, offset=-320.0,
                source_ratio=(1.0, 2.0, 0.0), texture="NONE", dimension=3, binning=None,
-               spectral_index=-2.0, flat_llh=1.0, scale_fixed=0.0):
+               spectral_index=-2.0, flat_llh=1.0, scale_fixed=0.0, sm_fixed=None, src_columns=None):
     """Flatten (paramset, args) into the oracle's POD model.
 
     `source_ratio` is used as given (the scripts normalise it first, scripts/fr.py:118).
@@ -214,10 +214,12 @@ def make_model(paramset, mode, *, bestfit_fr=(1 / 3, 1 / 3, 1 / 3), smearing=0.0
             m.idx_sm[k] = sm_idx[k] if len(sm_idx) == 4 else -1
         m.idx_mass[0] = m.idx_mass[1] = -1
     for k in range(4):
-        m.sm_fixed[k] = NUFIT_ANGLES[k]
+        m.sm_fixed[k] = float(sm_fixed[k]) if sm_fixed is not None else NUFIT_ANGLES[k]
     m.mass_fixed[0], m.mass_fixed[1] = MASS_EIGENVALUES
 
     src_idx = [i for i, t in enumerate(tags) if t == "SRCANGLES"]
+    if src_columns is not None:
+        src_idx = [int(x) for x in src_columns]
     if len(src_idx) == 2:
         m.idx_src[0], m.idx_src[1] = src_idx
     else:

@@ -18,7 +18,11 @@ def golden():
     """Golden vectors generated from the reference (tests/golden/make_golden.py)."""
     path = os.path.join(ROOT, "tests", "golden", "golden.npz")
     with np.load(path, allow_pickle=False) as z:
-        return {k: z[k] for k in z.files}
+        out = {k: z[k] for k in z.files}
+    # G10 (examples/tutorial.ipynb posterior) lives in its own file, tests/golden/make_golden_tutorial.py
+    with np.load(os.path.join(ROOT, "tests", "golden", "golden_tutorial.npz"), allow_pickle=False) as z:
+        out.update({k: z[k] for k in z.files})
+    return out
 
 
 @pytest.fixture(scope="session")

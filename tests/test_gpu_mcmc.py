@@ -188,3 +188,23 @@ def test_reference_named_entry_points(golden):
     n0 = len(llh_utils._BOUND)
     f(th[:3])
     assert len(llh_utils._BOUND) == n0
+
+
+def test_tutorial_chain_reproduces_stored_notebook_outputs(golden, capsys):
+    """examples/tutorial.ipynb:611-619 stores the outputs of its chain (60 walkers, 1000 + 10000 steps): sum of
+    acceptance fractions 42.9055 (mean 0.715) and autocorrelation times 30-31.  emcee is un-vendored and unseeded
+    there, so the check is distributional."""
+    asimov, ps = Cf.tutorial_paramsets(golden["g10_asimov_angles"])
+    f = llh_utils.tutorial_ln_prob(asimov, ps)
+    np.random.seed(26)
+    p0 = mcmc_utils.flat_seed(ps, nwalkers=60)
+    samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=2, nwalkers=60, burnin=1000, nsteps=10000, seed=4)
+    out = capsys.readouterr().out
+    assert samples.shape == (600000, 2)
+    acc = float(out.split("sum of acceptance fraction")[1].split()[0])
+    assert 41.0 < acc < 45.0                                   # notebook: 42.9055
+    tau = np.array(out.split("autocorrelation")[1].replace("[", " ").replace("]", " ").split()[:2], dtype=float)
+    assert np.all(tau > 22) and np.all(tau < 40)               # notebook: [30.39 30.96]
+    # the posterior sits on the injected flavor angles
+    assert np.allclose(samples.mean(axis=0), golden["g10_asimov_angles"], atol=0.01)
+    f.close()

@@ -416,6 +416,24 @@ def test_max_bins_64(oracle):
 
 
 # ---------------------------------------------------------------- every specialisation of the fast SM kernel
+def test_tutorial_posterior_vs_golden(golden):
+    """examples/tutorial.ipynb (2-dim: the measured flavor angles themselves, flat priors, no oscillation)
+    against G10, generated from the reference."""
+    from golemflavor_amd import llh as llh_utils
+    asimov, ps = Cf.tutorial_paramsets(golden["g10_asimov_angles"])
+    f = llh_utils.tutorial_ln_prob(asimov, ps)
+    th, ref = golden["g10_theta"], golden["g10_lnprob"]
+    lp, fr, st = f.model.lnprob(th, want_fr=True)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isinf(lp), ~fin)
+    assert rel_err(lp[fin], ref[fin]) <= REL
+    assert np.abs(fr[fin] - golden["g10_fr"][fin]).max() <= ABS_FR
+    assert np.all(st[th[:, 0] < 0] == _lib.GF_ST_OUT_OF_PRIOR)
+    # the callable keeps the notebook's conventions
+    assert isinstance(f(th[0]), float) and f([-0.1, 0.2]) == -np.inf
+    f.close()
+
+
 def test_cp_phase_outside_zero_two_pi(golden, oracle):
     """The fast cosine folds [0, 2 pi]; a paramset that boxes dcp elsewhere (here [-pi, 3 pi]) takes the general
     Cody-Waite path and must agree with the oracle just the same; C-ABI argument checks on the way."""

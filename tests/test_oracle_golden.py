@@ -137,3 +137,20 @@ def test_g9_lnprob_12dim(golden, oracle):
         else:
             assert s[0] in (0, 1)
             assert rel_err(lp, [v]) <= 1e-11
+
+
+def test_g10_tutorial_posterior(golden, oracle):
+    """examples/tutorial.ipynb cells 33/35: the two flavor angles are theta, no mixing.  The oracle expresses it
+    as the Gaussian posterior with the identity for a mixing matrix; its u_to_fr divides by sum(src) once more
+    than the notebook does, hence one rounding (2e-16) instead of bit equality."""
+    from golemflavor_amd import configs as Cf
+    _, ps = Cf.tutorial_paramsets(golden["g10_asimov_angles"])
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=golden["g10_bestfit_fr"], smearing=0.02,
+                           sm_fixed=(0, 1, 0, 0), src_columns=(0, 1))
+    lp, fr = oracle.lnprob_batch(om, golden["g10_theta"], want_fr=True)
+    ref = golden["g10_lnprob"]
+    assert np.array_equal(np.isinf(lp), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert fin.sum() > 3000 and (~fin).sum() > 50
+    assert np.abs(lp[fin] - ref[fin]).max() <= 4e-16 * np.abs(ref[fin]).max()
+    assert np.abs(fr[fin] - golden["g10_fr"][fin]).max() <= 3e-16
