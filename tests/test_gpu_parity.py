@@ -194,6 +194,17 @@ def test_propagate_and_haar(golden, oracle):
         assert abs(gang[:, 0].mean() - 0.5) < 0.02 and abs(gang[:, 3].mean() - np.pi) < 0.1
 
 
+def test_docs_known_answers_on_the_gpu():
+    """docs/source/physics.rst:277-279 and examples/tutorial.ipynb:165: NuFIT mixing applied to the three
+    benchmark sources, to the two decimals the reference's documentation prints."""
+    ps = Cf.unitary_paramset()
+    nufit = np.array([Cf.NUFIT_ANGLES], dtype=float)
+    for src, want in (((1, 2, 0), (0.31, 0.35, 0.34)), ((0, 1, 0), (0.18, 0.44, 0.38)), ((1, 0, 0), (0.55, 0.18, 0.27))):
+        with Model(compile_model(ps, "PRIOR_ONLY", source_ratio=np.array(src, dtype=float) / sum(src))) as m:
+            fr, st = m.propagate(nufit)
+        assert st[0] == 0 and np.allclose(np.round(fr[0], 2), want, atol=1e-12), (src, fr[0])
+
+
 # ---------------------------------------------------------------- BSM path
 def _status_must_agree(oracle, om, theta):
     """Rows on which the NON_UNITARY verdict is decidable.  The reference's assert (fr.py:493-494) fires
