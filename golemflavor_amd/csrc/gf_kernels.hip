@@ -452,6 +452,7 @@ hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* ptab, const doub
                                double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     switch (c.ndim) {
+    case 2: return launch_lnprob_sm_n<2>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);   // examples/tutorial.ipynb
     case 4: return launch_lnprob_sm_n<4>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
     case 6: return launch_lnprob_sm_n<6>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
     case 7: return launch_lnprob_sm_n<7>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
