@@ -74,9 +74,20 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / GF_WAVE);        // wave-uniform -> SALU
     double* tile = tiles[wave];
-    const int stride = gridDim.x * GF_WAVES_PER_BLOCK;
-    int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave;
-    if (t >= nfull) return;
+    // Workgroups are dealt round-robin to the 8 XCDs of an MI355X; each XCD (own L2, own path to the fabric)
+    // streams one contiguous eighth of the batch instead of every eighth tile group of all of it.  Measured within
+    // the +-2 % run-to-run noise of the plain grid-stride order (GF_NO_XCD_MAP) on this pure stream -- there is no
+    // reuse for an L2 to keep -- two interleaved A/B runs in profiles/r01/ab_xcd_contiguous.txt.
+#ifndef GF_NO_XCD_MAP
+    const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
+#else
+    const int nx = 1;
+#endif
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx;
+    const int64_t tend = nfull * (xcd + 1) / nx;
+    const int stride = (gridDim.x / nx) * GF_WAVES_PER_BLOCK;
+    int64_t t = nfull * xcd / nx + (int64_t)lb * GF_WAVES_PER_BLOCK + wave;
+    if (t >= tend) return;
 
     // PD tiles of this wave are in flight in registers (software pipeline of depth PD); a tile index past
     // the end is clamped to the wave's last valid tile (a redundant but harmless re-read at the tail).
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
     d2_t pre[PD][VPL];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
-        const int64_t tp = (t + (int64_t)p * stride < nfull) ? t + (int64_t)p * stride : t;
+        const int64_t tp = (t + (int64_t)p * stride < tend) ? t + (int64_t)p * stride : t;
         const d2_t* src = reinterpret_cast<const d2_t*>(theta + tp * (GF_WAVE * NDIM));
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
     // (Measured neutral on MI355X at 4 waves/SIMD -- other waves cover it -- kept because it is free.)
     double val_prev = 0.0;
     int64_t i_prev = -1;
-    for (; t < nfull; t += stride) {
+    for (; t < tend; t += stride) {
         // oldest tile in flight: registers -> LDS; shift the pipeline; fetch the tile PD strides ahead
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
             for (int j = 0; j < VPL; ++j) pre[p][j] = pre[p + 1][j];
 #ifndef GF_NO_LOADS
         const int64_t ta = t + (int64_t)PD * stride;
-        const int64_t tn = (ta < nfull) ? ta : t;
+        const int64_t tn = (ta < tend) ? ta : t;
         const d2_t* src = reinterpret_cast<const d2_t*>(theta + tn * (GF_WAVE * NDIM));
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
