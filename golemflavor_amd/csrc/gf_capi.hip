@@ -86,6 +86,7 @@ namespace {
 // one small block of device memory for its constant tables.  A grid scan creates and destroys hundreds of
 // models (one per grid point); hipStreamCreate / hipMalloc / hipFree / hipGetDeviceProperties cost ~1 ms each
 // and hipFree synchronises the device, so destroyed models hand their stream and block back to this pool.
+constexpr int64_t GF_ZEROCOPY_MAX_ROWS = 2048;
 constexpr int POOL_MAX_DEVICES = 64;
 constexpr size_t POOL_MAX_ITEMS = 1024;
 constexpr size_t CONST_PTAB_BYTES = sizeof(double) * GF_MAX_DIM * 4;
@@ -500,6 +501,22 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     double* h_fr = h_out + m->cap;
     int32_t* h_st = (int32_t*)(h_fr + 3 * m->cap);
     std::memcpy(h_theta, theta, sizeof(double) * nd * n);
+    // Small batches (emcee's half-ensemble of a 100-walker chain is 50 rows): the kernel reads theta from and
+    // writes its results to the pinned, device-mapped staging buffer directly -- one launch and one stream
+    // sync instead of launch + two DMA transfers, each of which costs more than the kilobytes they move.
+    static const bool zc_off = std::getenv("GF_NO_ZEROCOPY") != nullptr;       // diagnostics / A-B
+    if (n <= GF_ZEROCOPY_MAX_ROWS && !zc_off) {
+        if (with_llh)
+            rc = launch_lnprob(m, m->stream, h_theta, GF_LAYOUT_AOS, n, h_out, fr ? h_fr : nullptr, status ? h_st : nullptr);
+        else
+            rc = launch_propagate(m, m->stream, h_theta, GF_LAYOUT_AOS, n, h_fr, status ? h_st : nullptr);
+        if (rc != GF_OK) return rc;
+        GF_HIP(hipStreamSynchronize(m->stream));
+        if (with_llh) std::memcpy(lnprob, h_out, sizeof(double) * n);
+        if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
+        if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
+        return GF_OK;
+    }
     GF_HIP(hipMemcpyAsync(m->d_theta, h_theta, sizeof(double) * nd * n, hipMemcpyHostToDevice, m->stream));
     double* d_ln = m->d_out;
     double* d_fr = m->d_out + m->cap;

@@ -396,7 +396,9 @@ hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const doub
 {
     int64_t first = 0;
     if constexpr (NDIM != 0) {
-        const int64_t nfull = n / GF_WAVE;
+        int64_t nfull = n / GF_WAVE;
+        // a small ragged batch (emcee's half-ensembles) is one launch of the generic kernel, not fast + tail
+        if (n <= 2048 && n % GF_WAVE != 0) nfull = 0;
         if (layout == 0 && nfull > 0) {
 #ifdef GF_EXPERIMENTAL_RING
             static const bool use_ring = std::getenv("GF_SM_RING") != nullptr;

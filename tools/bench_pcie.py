@@ -8,7 +8,7 @@ from bench import notebook_descriptor, synth_theta
 from golemflavor_amd.model import Model
 ps, bf, desc = notebook_descriptor()
 with Model(desc) as m:
-    for n in (100, 4096, 65536, 1 << 20, 1 << 22):
+    for n in (50, 100, 512, 2048, 4096, 65536, 1 << 20, 1 << 22):
         th = synth_theta(ps, n, 1)
         for _ in range(3):
             m.lnprob(th, want_status=False)
@@ -17,4 +17,4 @@ with Model(desc) as m:
         for _ in range(reps):
             m.lnprob(th, want_status=False)
         dt = (time.perf_counter() - t0) / reps
-        print(json.dumps({"n": n, "us_per_call": dt * 1e6, "evals_per_s": n / dt, "GBps_over_pcie": n * 56 / dt / 1e9}))
+        print(json.dumps({"zerocopy": "off" if os.environ.get("GF_NO_ZEROCOPY") else "auto", "n": n, "us_per_call": dt * 1e6, "evals_per_s": n / dt, "GBps_over_pcie": n * 56 / dt / 1e9}))
