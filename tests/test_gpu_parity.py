@@ -445,6 +445,36 @@ def test_tutorial_posterior_vs_golden(golden):
     f.close()
 
 
+def test_plain_c_consumer_of_the_abi(golden, nb_model, tmp_path):
+    """tests/cabi/smoke.c: a C99 program that fills gf_model_desc by hand and calls gf_lnprob_batch -- the boundary
+    without Python in the way.  Same numbers as the ctypes path, bit for bit, and the golden values to 1e-10."""
+    import os
+    import subprocess
+    from golemflavor_amd.descriptor import log_gauss_mass
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "cabi", "smoke.c"), "-o", exe, "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH),
+                        "-lm", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    th = golden["g6_theta"][4000:4400]                       # seed-box rows, then full-range rows incl. out-of-prior
+    loc, sig = (0.307, (1 - 0.02206) ** 2, 0.538), (0.013, 0.00147, 0.069)
+    masses = [repr(log_gauss_mass((0 - m) / s_, (1 - m) / s_)) for m, s_ in zip(loc, sig)]
+    args = [repr(float(x)) for x in golden["g6_bestfit_fr"]] + masses
+    text = "\n".join(" ".join(repr(float(v)) for v in row) for row in th) + "\n"
+    r = subprocess.run([exe] + args, input=text, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = np.array([[float(x) for x in line.split()] for line in r.stdout.strip().splitlines()])
+    assert out.shape == (len(th), 5)
+    lp, fr, st = nb_model.lnprob(th, want_fr=True)
+    assert np.array_equal(out[:, 0], lp, equal_nan=True) and np.array_equal(out[:, 4].astype(np.int32), st)
+    assert np.array_equal(out[:, 1:4], fr, equal_nan=True)
+    ref = golden["g6_lnprob"][4000:4400]
+    fin = np.isfinite(ref)
+    assert fin.sum() > 50 and rel_err(out[fin, 0], ref[fin]) <= REL
+
+
 def test_cp_phase_outside_zero_two_pi(golden, oracle):
     """The fast cosine folds [0, 2 pi]; a paramset that boxes dcp elsewhere (here [-pi, 3 pi]) takes the general
     Cody-Waite path and must agree with the oracle just the same; C-ABI argument checks on the way."""

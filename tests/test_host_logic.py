@@ -276,3 +276,14 @@ def test_host_multi_gaussian_matches_golden(golden):
     fin = np.isfinite(ref)
     assert np.abs(got[fin] - ref[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
     assert np.isinf(ref).sum() > 10 and fin.sum() > 100
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/golemflavor_hip.h is consumed by C, not only by the C++ translation units that implement it:
+    the C consumer under tests/cabi must compile warning-free as strict C99."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = str(tmp_path / "smoke.o")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"),
+                        "-c", os.path.join(root, "tests", "cabi", "smoke.c"), "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
