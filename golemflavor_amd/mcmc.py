@@ -311,20 +311,21 @@ class DeviceEnsembleSampler:
                                                      lnp.ctypes.data_as(self._lib._dp)), "gf_sampler_get_state")
         return (pos[0], lnp[0]) if self.nchains == 1 else (pos, lnp)
 
-    def _fetch(self):
+    def _fetch(self, chain=False, lnprob=False, naccepted=False):
+        """Only what is asked for crosses PCIe (the C entry point skips NULL arrays)."""
         ns = int(self._L.gf_sampler_nstored(self._h))
-        chain = np.empty((self.nchains, ns, self.k, self.dim))
-        lnp = np.empty((self.nchains, ns, self.k))
-        nacc = np.empty((self.nchains, self.k), dtype=np.uint32)
+        c = np.empty((self.nchains, ns, self.k, self.dim)) if chain else None
+        lnp = np.empty((self.nchains, ns, self.k)) if lnprob else None
+        nacc = np.empty((self.nchains, self.k), dtype=np.uint32) if naccepted else None
         self._lib.check(self._L.gf_sampler_get_chain(
-            self._h, chain.ctypes.data_as(self._lib._dp), lnp.ctypes.data_as(self._lib._dp),
-            nacc.ctypes.data_as(self._C.POINTER(self._C.c_uint32)), None), "gf_sampler_get_chain")
-        return chain, lnp, nacc
+            self._h, c.ctypes.data_as(self._lib._dp) if chain else None, lnp.ctypes.data_as(self._lib._dp) if lnprob else None,
+            nacc.ctypes.data_as(self._C.POINTER(self._C.c_uint32)) if naccepted else None, None), "gf_sampler_get_chain")
+        return c, lnp, nacc
 
     @property
     def chain(self):
         """(nwalkers, nsteps, ndim) like emcee-2 [(nchains, nwalkers, nsteps, ndim) when nchains > 1]."""
-        c = np.ascontiguousarray(self._fetch()[0].transpose(0, 2, 1, 3))
+        c = np.ascontiguousarray(self._fetch(chain=True)[0].transpose(0, 2, 1, 3))
         return c[0] if self.nchains == 1 else c
 
     @property
@@ -334,12 +335,12 @@ class DeviceEnsembleSampler:
 
     @property
     def lnprobability(self):
-        lp = np.ascontiguousarray(self._fetch()[1].transpose(0, 2, 1))
+        lp = np.ascontiguousarray(self._fetch(lnprob=True)[1].transpose(0, 2, 1))
         return lp[0] if self.nchains == 1 else lp
 
     @property
     def acceptance_fraction(self):
-        nacc = self._fetch()[2].astype(np.float64) / max(self.iterations, 1)
+        nacc = self._fetch(naccepted=True)[2].astype(np.float64) / max(self.iterations, 1)
         return nacc[0] if self.nchains == 1 else nacc
 
     def postprocess(self, want_fr=True, want_status=False, nbins=None, models=None, step_major=False):
@@ -381,7 +382,7 @@ class DeviceEnsembleSampler:
         """The stored samples in the order the device holds them, (nsteps*nwalkers, ndim) [leading chain axis
         when nchains > 1]: `flatchain` without the transposition to emcee's walker-major order -- for
         consumers that treat the chain as a bag of samples (histograms, post-processing)."""
-        c = self._fetch()[0]
+        c = self._fetch(chain=True)[0]
         c = c.reshape(self.nchains, -1, self.dim)
         return c[0] if self.nchains == 1 else c
 
