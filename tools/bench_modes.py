@@ -55,3 +55,23 @@ for name, ps, kw, want_fr, want_st in cases:
         b = 8 * nd + 8 + (24 if want_fr else 0) + (4 if want_st else 0)
         print(json.dumps({"case": name, "ndim": nd, "bytes_per_eval": b, "kernel_ms": round(ms, 4), "evals_per_s": N / ms * 1e3,
                           "GBps_algorithmic": N * b / ms / 1e6, "frac_hbm_peak": round(N * b / ms / 1e6 / 8000, 3)}), flush=True)
+
+# the same notebook posterior from an SoA buffer ([ndim][n]); goes through the generic kernel
+name, ps, kw = cases[0][0], cases[0][1], dict(cases[0][2])
+mode = kw.pop("mode")
+box = np.array(ps.seeds, dtype=float)
+blk = rng.uniform(box[:, 0], box[:, 1], size=(1 << 20, 6))
+th = np.ascontiguousarray(np.tile(blk, (N >> 20, 1)).T)
+with Model(compile_model(ps, mode, **kw)) as m:
+    d_th = m.alloc(th.nbytes).upload(th)
+    d_out = m.alloc(8 * N)
+    for _ in range(3):
+        m.lnprob_device(d_th.ptr, N, d_out.ptr, None, None, layout=1)
+    e0, e1 = m.event(), m.event()
+    m.sync(); e0.record()
+    for _ in range(20):
+        m.lnprob_device(d_th.ptr, N, d_out.ptr, None, None, layout=1)
+    e1.record(); m.sync()
+    ms = e0.elapsed_ms(e1) / 20
+    print(json.dumps({"case": name + " (SoA input, generic kernel)", "ndim": 6, "bytes_per_eval": 56, "kernel_ms": round(ms, 4),
+                      "evals_per_s": N / ms * 1e3, "GBps_algorithmic": N * 56 / ms / 1e6, "frac_hbm_peak": round(N * 56 / ms / 1e6 / 8000, 3)}))
