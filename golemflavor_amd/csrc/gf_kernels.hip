@@ -148,97 +148,10 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
     if (i_prev >= 0) GF_STORE_OUT(lnprob + i_prev, val_prev);
 }
 
-#ifdef GF_EXPERIMENTAL_RING
-// EXPERIMENT, not built by default (-DGF_EXPERIMENTAL_RING, then GF_SM_RING=1 at run time; see
-// profiles/r01/ring_ab.log: parity-green but 230 us vs 183 us for k_lnprob_sm_fast, so it is not the product path).
-// Loader / consumer variant of the hot kernel.
-// One loader wave per 512-thread block streams tiles HBM -> LDS with LDS-DMA (global_load_lds_dwordx4,
-// no VGPR staging, RING_DEPTH tiles in flight) into a RING_SLOTS-deep ring; seven consumer waves take
-// tiles round-robin, evaluate them straight out of the slot and hand it back.  Slot ownership travels in
-// one LDS word per slot (0 = free, k+1 = holds the block's k-th tile).  Every spin is bounded: a broken
-// handshake sets *err and the kernel still terminates.
-constexpr int RING_SLOTS = 24;
-constexpr int RING_DEPTH = 8;
-constexpr int RING_SPIN_MAX = 1 << 22;
-typedef __attribute__((address_space(3))) char* lds_cptr;
-typedef volatile __attribute__((address_space(3))) int* lds_iptr;
+#if defined(GF_ASM_PIPE) || defined(GF_EXPERIMENTAL_RING)
+#include "gf_sm_experiments.hpp"   // measured alternatives, not built by default
+#endif
 
-template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
-__global__ __launch_bounds__(512, 2) void k_lnprob_sm_ring(const GfCommon c, const double* __restrict__ ptab,
-                                                           const double* __restrict__ theta, int64_t nfull,
-                                                           double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                           int32_t* __restrict__ status, int* __restrict__ err)
-{
-    static_assert(NDIM > 0 && (NDIM % 2) == 0, "ring path: whole 1-KiB DMA pieces per tile");
-    constexpr int TILE_B = GF_WAVE * NDIM * 8;
-    constexpr int NDMA = TILE_B / 1024;
-    constexpr int NC = 7;
-    // ONE shared object (LDS offset 0): ring | slot flags | prior table
-    __shared__ __attribute__((aligned(16))) char smem[RING_SLOTS * TILE_B + 128 + GF_MAX_DIM * 4 * 8];
-    lds_iptr full = (lds_iptr)((lds_cptr)smem + RING_SLOTS * TILE_B);
-    double* ctab = reinterpret_cast<double*>(smem + RING_SLOTS * TILE_B + 128);
-    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
-    if (threadIdx.x < RING_SLOTS) full[threadIdx.x] = 0;
-    __syncthreads();
-
-    const int lane = threadIdx.x & (GF_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / GF_WAVE);
-    const int64_t nb = gridDim.x;
-    const int64_t kb = (nfull - blockIdx.x + nb - 1) / nb;           // this block's tiles: t = blockIdx.x + k nb
-    const unsigned ring_base = (unsigned)(size_t)(lds_cptr)smem;
-
-    if (wave == 0) {
-        for (int64_t k = 0; k < kb; ++k) {
-            const int slot = (int)(k % RING_SLOTS);
-            int spins = 0;
-            while (full[slot] != 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > RING_SPIN_MAX) { if (lane == 0) *err = 1; return; }
-            }
-            const int64_t t = blockIdx.x + k * nb;
-            const char* src = reinterpret_cast<const char*>(theta + t * (GF_WAVE * NDIM)) + lane * 16;
-            const unsigned dst = ring_base + slot * TILE_B;
-#pragma unroll
-            for (int j = 0; j < NDMA; ++j) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src + j * 1024), "s"(dst + j * 1024) : "memory");
-            }
-            if (k >= RING_DEPTH - 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA * (RING_DEPTH - 1)) : "memory");
-                const int64_t kp = k - (RING_DEPTH - 1);
-                if (lane == 0) full[(int)(kp % RING_SLOTS)] = (int)(kp + 1);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int64_t kp = (kb > RING_DEPTH - 1 ? kb - (RING_DEPTH - 1) : 0); kp < kb; ++kp)
-            if (lane == 0) full[(int)(kp % RING_SLOTS)] = (int)(kp + 1);
-    } else {
-        const int cidx = wave - 1;
-        for (int64_t k = cidx; k < kb; k += NC) {
-            const int slot = (int)(k % RING_SLOTS);
-            int spins = 0;
-            while (full[slot] != (int)(k + 1)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > RING_SPIN_MAX) { if (lane == 0) *err = 2; return; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const double* row = reinterpret_cast<const double*>(smem + slot * TILE_B) + lane * NDIM;
-            double val, fr[3];
-            int st;
-            eval_walker<NDIM, MODE, SAMPLED, WANT_FR>(c, ctab, row, NDIM, val, fr, st);
-            // all lanes are done with the slot (val depends on every read): hand it back
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) full[slot] = 0;
-            const int64_t i = (blockIdx.x + k * nb) * GF_WAVE + lane;
-            GF_STORE_OUT(lnprob + i, val);
-            if (WANT_FR) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
-            if (status) status[i] = st;
-        }
-    }
-}
-#endif  // GF_EXPERIMENTAL_RING
 
 // Generic kernel: any layout, runtime row length, ragged tiles; walkers [first, n) of the batch.
 template <int NDIM, int MODE>
@@ -423,9 +336,22 @@ hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const doub
             const bool sampled = c.idx_sm[0] >= 0 && c.idx_sm[1] >= 0 && c.idx_sm[2] >= 0 && c.idx_sm[3] >= 0 &&
                                  c.idx_src[0] >= 0 && c.idx_src[1] >= 0;
 #define GF_GO(S, F) hipLaunchKernelGGL((k_lnprob_sm_fast<NDIM, MODE, S, F>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull, lnprob, fr, status)
+            bool piped = false;
+#ifdef GF_ASM_PIPE
+            if constexpr (NDIM == 6 || NDIM == 4) {
+                const bool canon6 = sampled && NDIM >= 6 && c.idx_sm[0] == 0 && c.idx_sm[1] == 1 && c.idx_sm[2] == 2 &&
+                                    c.idx_sm[3] == 3 && c.idx_src[0] == 4 && c.idx_src[1] == 5;
+                if (!fr && (canon6 || MODE == MODE_PRIOR_ONLY)) {
+                    if (canon6) hipLaunchKernelGGL((k_lnprob_sm_pipe<NDIM, MODE, 2>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull, lnprob, status);
+                    else hipLaunchKernelGGL((k_lnprob_sm_pipe<NDIM, MODE, 0>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, nfull, lnprob, status);
+                    piped = true;
+                }
+            }
+#endif
             const bool canon = sampled && NDIM >= 6 && c.idx_sm[0] == 0 && c.idx_sm[1] == 1 && c.idx_sm[2] == 2 &&
                                c.idx_sm[3] == 3 && c.idx_src[0] == 4 && c.idx_src[1] == 5;
-            if (canon)        { if (fr) GF_GO(2, true); else GF_GO(2, false); }
+            if (piped)        { }
+            else if (canon)   { if (fr) GF_GO(2, true); else GF_GO(2, false); }
             else if (sampled) { if (fr) GF_GO(1, true); else GF_GO(1, false); }
             else              { if (fr) GF_GO(0, true); else GF_GO(0, false); }
 #undef GF_GO
