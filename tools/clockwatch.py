@@ -25,6 +25,17 @@ rng = np.random.default_rng(1)
 box = np.array(nb.seeds, dtype=float)
 th = np.tile(rng.uniform(box[:, 0], box[:, 1], size=(1 << 20, 6)), (N >> 20, 1))
 kw = dict(bestfit_fr=bf, smearing=0.02) if which == "sm_gauss" else {}
+BYTES = 56
+if which == "bsm":                     # the 12-dim BSM posterior (C5), 4 M walkers per launch, no status
+    from golemflavor_amd.enums import Texture
+    _, nb = Cf.fr_paramsets(6, (0.4444, 0.0))
+    N = 1 << 22
+    BYTES = 104
+    box = np.array(nb.seeds, dtype=float)
+    th = np.tile(rng.uniform(box[:, 0], box[:, 1], size=(1 << 20, 12)), (N >> 20, 1))
+    th[:, 11] = rng.uniform(-56, -36, N)
+    kw = dict(bestfit_fr=(1 / 3,) * 3, smearing=0.02, texture=Texture.OET, dimension=6, binning=Cf.default_bin_edges(),
+              source_ratio=(0., 1., 0.))
 samples = []
 stop = False
 
@@ -41,7 +52,8 @@ def watch():
         time.sleep(0.5)
 
 
-with Model(compile_model(nb, "SM_GAUSS" if which == "sm_gauss" else "PRIOR_ONLY", **kw)) as m:
+MODE = {"sm_gauss": "SM_GAUSS", "prior_only": "PRIOR_ONLY", "bsm": "BSM_GAUSS"}[which]
+with Model(compile_model(nb, MODE, **kw)) as m:
     d_th = m.alloc(th.nbytes).upload(th)
     d_out = m.alloc(8 * N)
     t = threading.Thread(target=watch, daemon=True)
@@ -51,11 +63,12 @@ with Model(compile_model(nb, "SM_GAUSS" if which == "sm_gauss" else "PRIOR_ONLY"
     n = 0
     m.sync(); e0.record()
     while time.time() < t_end:
-        for _ in range(200):
+        reps = 200 if which != "bsm" else 40
+        for _ in range(reps):
             m.lnprob_device(d_th.ptr, N, d_out.ptr, None, None)
         m.sync()
-        n += 200
+        n += reps
     e1.record(); m.sync()
     stop = True
     ms = e0.elapsed_ms(e1) / n
-print(json.dumps({"kernel": which, "kernel_ms": round(ms, 4), "GBps": round(N * 56 / ms / 1e6), "samples": samples[2:8]}, indent=0))
+print(json.dumps({"kernel": which, "kernel_ms": round(ms, 4), "evals_per_s": N / ms * 1e3, "GBps": round(N * BYTES / ms / 1e6), "samples": samples[2:8]}, indent=0))
