@@ -18,6 +18,52 @@ def test_shard_partition_is_exact():
         gdist.shard(4, 2, 2)
 
 
+def test_gather_chains_for_any_grid_and_world():
+    """Property (hypothesis): for any number of grid points and ranks -- including ranks that own no point and
+    grids that do not divide evenly -- every rank ends up with every point's block, in grid order.  The ranks
+    run as threads; the all-gather is a barrier plus a shared slot table."""
+    import threading
+    from hypothesis import given, settings, strategies as st
+
+    class ThreadBackend:
+        def __init__(self, rank, world, slots, barrier):
+            self.rank, self.world, self._slots, self._barrier = rank, world, slots, barrier
+
+        def allgather(self, arr):
+            self._slots[self.rank] = np.array(arr)
+            self._barrier.wait()
+            out = np.stack([self._slots[q] for q in range(self.world)])
+            self._barrier.wait()                      # nobody overwrites a slot before everybody has read it
+            return out
+
+    @settings(max_examples=40, deadline=None)
+    @given(n=st.integers(1, 23), world=st.integers(2, 7), rows=st.integers(1, 4))
+    def check(n, world, rows):
+        blocks = {g: np.full((rows, 3), float(g)) + np.arange(3) for g in range(n)}
+        slots, barrier, results, errors = [None] * world, threading.Barrier(world), [None] * world, []
+
+        def run(rank):
+            try:
+                local = {g: blocks[g] for g in gdist.shard(n, rank, world)}
+                results[rank] = gdist.gather_chains(local, n, ThreadBackend(rank, world, slots, barrier))
+            except Exception as exc:       # noqa: BLE001
+                errors.append(exc)
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=30)
+        assert not errors, errors
+        for r in range(world):
+            assert len(results[r]) == n
+            for g in range(n):
+                assert np.array_equal(results[r][g], blocks[g])
+
+    check()
+
+
 def test_local_backend_roundtrip():
     b = gdist.LocalBackend()
     chains = gdist.run_grid([0.1, 0.2, 0.3], lambda p, g: np.full((4, 2), p + g), b)
