@@ -731,12 +731,17 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             pa.nwalkers = s->nwalkers; pa.pos = s->d_pos; pa.lnp = s->d_lnp; pa.naccept = s->d_naccept;
             pa.chain = store ? s->d_chain : nullptr; pa.lnp_chain = store ? s->d_lnp_chain : nullptr;
             pa.nstore_cap = s->nstore_cap; pa.seed = s->seed; pa.thin = thin; pa.store = store ? 1 : 0; pa.a = s->a;
-            constexpr int64_t CHUNK = 1 << 16;                          // steps per launch (multiple of any thin <= 2^16? no: see below)
+            constexpr int64_t CHUNK = 1 << 16;                          // steps per launch: bounds a kernel's run time
             int64_t done_p = 0;
             while (done_p < nsteps) {
-                // a chunk boundary must fall on a stored step so that (step % thin) restarts at 0: whole multiples of thin
+                // every launch but the last covers a whole multiple of `thin` steps, so that the kernel's
+                // (step % thin) == 0 test, which counts from the launch's first step, stays aligned with the run
                 int64_t count = nsteps - done_p < CHUNK ? nsteps - done_p : CHUNK;
-                if (count < nsteps - done_p && thin > 1) count = (count / thin) * thin ? (count / thin) * thin : thin;
+                if (count < nsteps - done_p) {
+                    const int64_t whole = (count / thin) * thin;
+                    count = whole > 0 ? whole : thin;
+                    if (count > nsteps - done_p) count = nsteps - done_p;      // thin longer than what is left
+                }
                 pa.iteration_base = s->iteration + (uint64_t)done_p;
                 pa.store_base = s->nstored + (done_p + thin - 1) / thin;
                 pa.nsteps = count;
