@@ -239,6 +239,26 @@ def test_persistent_workgroup_sampler_equals_grid_sampler(golden, monkeypatch, n
     f.close()
 
 
+def test_persistent_sampler_across_launch_chunks(golden, monkeypatch):
+    """A persistent run is cut into launches of <= 65536 steps; the cut must fall on a multiple of `thin`."""
+    asimov, ps = notebook_sets(golden)
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    rng = np.random.default_rng(0)
+    p0 = uniform_theta(ps, 16, rng, seeds=True)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GF_SAMPLER_PERSIST", mode)
+        s = mcmc_utils.DeviceEnsembleSampler(16, 6, f, seed=5)
+        s.run_mcmc(p0, 66000, thin=7)
+        out[mode] = (s.chain, s.lnprobability, s.acceptance_fraction)
+        assert s.chain.shape == (16, (66000 + 6) // 7, 6) and s.iterations == 66000
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_PERSIST")
+    for x, y in zip(out["1"], out["0"]):
+        assert np.array_equal(x, y)
+    f.close()
+
+
 def test_device_sampler_bookkeeping_and_reset(golden):
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)
