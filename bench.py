@@ -166,7 +166,7 @@ def main():
             import threading
             th = threading.Thread(target=_rccl_setup, daemon=True)
             th.start()
-            th.join(timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "120")))
+            th.join(timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
             if th.is_alive():
                 rccl_error = "timeout: RCCL communicator setup did not finish"
                 hard_exit = True

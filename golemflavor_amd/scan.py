@@ -200,7 +200,7 @@ def main(argv=None):
     # the fallback when the communicator cannot be set up, and the control plane either way
     rccl, rccl_err, allgather = None, None, None
     if world > 1 or os.environ.get("GF_SCAN_RCCL"):
-        rccl, rccl_err = gdist.open_rccl(rank, world, device, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "120")))
+        rccl, rccl_err = gdist.open_rccl(rank, world, device, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
     if rccl is not None:
         stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
         allgather = lambda arr: rccl.allgather(arr, stage)  # noqa: E731
