@@ -173,3 +173,37 @@ def test_random_bsm_configurations(oracle, seed):
             assert rel_err(lp[clean], ref[clean]) <= REL, (seed, dim, tex, nbins)
         # propagate (no priors, no likelihood) gives the same composition as the lnprob kernel, bit for bit
         assert np.array_equal(pfr[good], fr[good])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GF_FUZZ_SEEDS_SAMPLER", "10"))))
+def test_random_sampler_shapes_are_launch_shape_independent(monkeypatch, seed):
+    """Device sampler on random (posterior structure, walkers, chains, steps, thinning): the one-workgroup-per-
+    ensemble launch shape and the per-half-step grid launch shape give bitwise the same chains, acceptance counts
+    and final state; stored lnprob is the batch kernel's evaluation of the stored position."""
+    from golemflavor_amd import mcmc as mcmc_utils
+    rng = np.random.default_rng(9000 + seed)
+    ps, mode = _random_paramset(rng)
+    nd = len(ps)
+    kw = dict(source_ratio=tuple(rng.dirichlet((1, 1, 1))))
+    if mode == "SM_GAUSS":
+        kw.update(bestfit_fr=tuple(rng.dirichlet((4, 3, 3))), smearing=float(rng.choice([0.05, 0.3])))
+    nwalkers = 2 * int(rng.integers(nd, 4 * nd + 40))
+    nchains = int(rng.choice([1, 2, 5]))
+    nsteps, thin = int(rng.integers(3, 50)), int(rng.choice([1, 1, 2, 5]))
+    box = np.array(ps.ranges, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nchains, nwalkers, nd))
+    out = {}
+    chain_seed = int(rng.integers(1, 2 ** 62))
+    with Model(compile_model(ps, mode, **kw)) as m:
+        for shape in ("1", "0"):
+            monkeypatch.setenv("GF_SAMPLER_PERSIST", shape)
+            s = mcmc_utils.DeviceEnsembleSampler(nwalkers, nd, m, nchains=nchains, seed=chain_seed)
+            s.run_mcmc(p0 if nchains > 1 else p0[0], nsteps, thin=thin)
+            out[shape] = (s.chain, s.lnprobability, s.acceptance_fraction, s.state[0], s.state[1])
+            s.close()
+        monkeypatch.delenv("GF_SAMPLER_PERSIST")
+        for x, y in zip(out["1"], out["0"]):
+            assert np.array_equal(x, y, equal_nan=True), (seed, mode, nd, nwalkers, nchains, nsteps, thin)
+        ch, lp = out["1"][0], out["1"][1]
+        again = m.lnprob(ch.reshape(-1, nd), want_status=False).reshape(lp.shape)
+        assert np.array_equal(again, lp, equal_nan=True)
