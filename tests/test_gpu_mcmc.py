@@ -208,3 +208,35 @@ def test_tutorial_chain_reproduces_stored_notebook_outputs(golden, capsys):
     # the posterior sits on the injected flavor angles
     assert np.allclose(samples.mean(axis=0), golden["g10_asimov_angles"], atol=0.01)
     f.close()
+
+
+def test_no_device_memory_leak_over_model_and_sampler_lifecycles(golden):
+    """A scan creates and destroys hundreds of models and samplers: device memory must come back (the per-device
+    pool keeps a stream and a 3-KB constant block per retired model, nothing else)."""
+    hip = C.CDLL("libamdhip64.so")
+    free0, free1, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    asimov, ps = notebook_sets(golden)
+    rng = np.random.default_rng(0)
+    p0 = rng.uniform(*np.array(ps.seeds, dtype=float).T, size=(2, 64, 6))
+
+    def cycle(k):
+        f = llh_utils.notebook_ln_prob(asimov, ps)
+        f(p0[0])                                              # host-buffer path: staging buffers
+        s = mcmc_utils.DeviceEnsembleSampler(64, 6, f, nchains=2, seed=k)
+        s.run_mcmc(p0, 40, thin=2)
+        s.postprocess(want_fr=True, nbins=8)
+        s.walker_mean()
+        s.close()
+        s2 = mcmc_utils.DeviceEnsembleSampler(64, 6, [f, f], seed=k)   # per-chain posteriors
+        s2.run_mcmc(p0, 20)
+        s2.close()
+        f.close()
+
+    for k in range(5):                                        # warm the pool and the runtime's own caches
+        cycle(k)
+    assert hip.hipMemGetInfo(C.byref(free0), C.byref(total)) == 0
+    for k in range(150):
+        cycle(100 + k)
+    assert hip.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
+    leaked = int(free0.value) - int(free1.value)
+    assert leaked < 32 << 20, "device memory shrank by %.1f MiB over 150 lifecycles" % (leaked / 2 ** 20)
