@@ -240,3 +240,46 @@ def test_no_device_memory_leak_over_model_and_sampler_lifecycles(golden):
     assert hip.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
     leaked = int(free0.value) - int(free1.value)
     assert leaked < 32 << 20, "device memory shrank by %.1f MiB over 150 lifecycles" % (leaked / 2 ** 20)
+
+
+def test_handles_are_independent_across_threads(golden):
+    """"Thread-safe per handle": different models / samplers driven from different host threads at the same time
+    (ctypes drops the GIL inside every call) give what they give alone."""
+    import threading
+    asimov, ps = notebook_sets(golden)
+    from golemflavor_amd.descriptor import compile_model
+    from golemflavor_amd.model import Model
+    th = np.ascontiguousarray(golden["g6_theta"][:3000])
+    bfs = [(1 / 3, 1 / 3, 1 / 3), (0.2, 0.45, 0.35), (0.5, 0.3, 0.2), (0.55, 0.18, 0.27)]
+    models = [Model(compile_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.05)) for bf in bfs]
+    want = [m.lnprob(th, want_status=False) for m in models]
+    rng = np.random.default_rng(1)
+    p0 = rng.uniform(*np.array(ps.seeds, dtype=float).T, size=(64, 6))
+
+    def chain_of(m, k):
+        s = mcmc_utils.DeviceEnsembleSampler(64, 6, m, seed=10 + k)
+        s.run_mcmc(p0, 60)
+        c = s.chain
+        s.close()
+        return c
+    want_chain = [chain_of(m, k) for k, m in enumerate(models)]
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(30):
+                n = 64 * (1 + (rep * 7 + k) % 40) + (rep % 3)
+                got = models[k].lnprob(th[:n], want_status=False)
+                assert np.array_equal(got, want[k][:n], equal_nan=True)
+            assert np.array_equal(chain_of(models[k], k), want_chain[k])
+        except Exception as exc:       # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(models))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for m in models:
+        m.close()
