@@ -258,6 +258,9 @@ const char* gf_strerror(int err)
 
 const char* gf_last_hip_error(void) { return g_err; }
 
+// internal (gf_sampler.hip, gf_comm.hip): one thread-local error text for the whole library
+void gf_internal_set_error(const char* msg) { std::snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 size_t gf_sizeof_model_desc(void) { return sizeof(gf_model_desc); }
 
 int gf_device_count(int* count)
@@ -422,7 +425,14 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         }
         const bool bsm = d->mode == GF_MODE_BSM_GAUSS;
         if (bsm) std::memcpy(img + CONST_BSM_OFFSET, &m->hb, sizeof(GfBsm));
-        e = hipMemcpy(m->d_block, img, bsm ? CONST_BLOCK_BYTES : CONST_PTAB_BYTES, hipMemcpyHostToDevice);
+        // stream-ordered, never the null stream: a synchronous hipMemcpy issued while another host thread is
+        // capturing a sampler graph fails on this runtime and poisons that capture.  The stream comes from the
+        // pool and goes straight back (the model gets its own only when an entry point needs one).
+        hipStream_t up = nullptr;
+        e = pool_stream(device, &up);
+        if (e == hipSuccess) e = hipMemcpyAsync(m->d_block, img, bsm ? CONST_BLOCK_BYTES : CONST_PTAB_BYTES, hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipStreamSynchronize(up);
+        if (up) pool_release(device, up, nullptr);
         m->d_ptab = reinterpret_cast<double*>(m->d_block);
         m->d_bsm = bsm ? reinterpret_cast<GfBsm*>(static_cast<unsigned char*>(m->d_block) + CONST_BSM_OFFSET) : nullptr;
     }

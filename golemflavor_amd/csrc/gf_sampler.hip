@@ -474,6 +474,7 @@ struct gf_sampler {
     int64_t nstore_cap = 0, nstored = 0;
     int64_t steps_since_reset = 0;
     StepState* d_state = nullptr;
+    StepState h_state = {};
     // captured graph of GRAPH_STEPS steps (2 nodes per step + one tick), valid for the chain pointers it was built with
     hipGraphExec_t graph = nullptr;
     double* graph_chain = nullptr;
@@ -486,6 +487,7 @@ int gf_model_internal(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, cons
                       int* device);
 int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, const double** d_ptab, int* device, int* cus,
                        int* nbins);
+void gf_internal_set_error(const char* msg);
 int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
                        double* d_fr, int32_t* d_status);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
@@ -493,10 +495,11 @@ int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int 
 }
 
 namespace {
-thread_local char g_serr[256] = "";
+thread_local char g_serr[256] = "";     // composed here, published through gf_last_hip_error()
 int sfail(hipError_t e, const char* what)
 {
     std::snprintf(g_serr, sizeof(g_serr), "%s: %s", what, hipGetErrorString(e));
+    gf_internal_set_error(g_serr);
     return GF_ERR_HIP;
 }
 #define GFS_HIP(call)                              \
@@ -508,7 +511,6 @@ int sfail(hipError_t e, const char* what)
 
 extern "C" {
 
-const char* gf_sampler_last_error(void) { return g_serr; }
 
 int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out)
 {
@@ -531,14 +533,18 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_naccept, sizeof(uint32_t) * nw);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, sizeof(uint32_t) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_state, sizeof(StepState));
-    if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(StepState));
-    if (e == hipSuccess) e = hipMemset(s->d_naccept, 0, sizeof(uint32_t) * nw);
-    if (e == hipSuccess) e = hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4);
+    // every transfer of this file goes through the sampler's stream: a synchronous (null-stream) hipMemcpy / hipMemset
+    // issued while ANOTHER host thread is capturing its sampler's graph fails and poisons that capture on this runtime
+    hipStream_t st0 = (hipStream_t)stream;
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_state, 0, sizeof(StepState), st0);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_naccept, 0, sizeof(uint32_t) * nw, st0);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_flags, 0, sizeof(uint32_t) * 4, st0);
     // device copies of the constants for the kernels that take them by pointer (k_stretch_persist)
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*));
-    if (e == hipSuccess) e = hipMemcpy(s->d_commons, c, sizeof(GfCommon), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)s->d_ptabs, &ptab, sizeof(void*), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_commons, c, sizeof(GfCommon), hipMemcpyHostToDevice, st0);
+    if (e == hipSuccess) e = hipMemcpyAsync((void*)s->d_ptabs, &ptab, sizeof(void*), hipMemcpyHostToDevice, st0);
+    if (e == hipSuccess) e = hipStreamSynchronize(st0);
     if (e != hipSuccess) { int rc = sfail(e, "gf_sampler_create"); gf_sampler_destroy(s); return rc; }
     *out = s;
     return GF_OK;
@@ -590,6 +596,7 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
         if (gf_model_constants(models[ch], &c, &htb[ch], &hpt[ch], &device, &cus, &nbins) != GF_OK || device != device0 ||
             c->ndim != c0->ndim || c->mode != c0->mode) {
             std::snprintf(g_serr, sizeof(g_serr), "gf_sampler_create_multi: model %d differs from model 0 in device, ndim or mode", ch);
+            gf_internal_set_error(g_serr);
             cleanup(); delete[] keep;
             return GF_ERR_INVALID_ARG;
         }
@@ -607,9 +614,11 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
     hipError_t e = hipMalloc((void**)&s->d_commons, sizeof(GfCommon) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_tbs, sizeof(void*) * nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_ptabs, sizeof(void*) * nchains);
-    if (e == hipSuccess) e = hipMemcpy(s->d_commons, hc, sizeof(GfCommon) * nchains, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)s->d_tbs, htb, sizeof(void*) * nchains, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)s->d_ptabs, hpt, sizeof(void*) * nchains, hipMemcpyHostToDevice);
+    hipStream_t st0 = (hipStream_t)stream0;
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_commons, hc, sizeof(GfCommon) * nchains, hipMemcpyHostToDevice, st0);
+    if (e == hipSuccess) e = hipMemcpyAsync((void*)s->d_tbs, htb, sizeof(void*) * nchains, hipMemcpyHostToDevice, st0);
+    if (e == hipSuccess) e = hipMemcpyAsync((void*)s->d_ptabs, hpt, sizeof(void*) * nchains, hipMemcpyHostToDevice, st0);
+    if (e == hipSuccess) e = hipStreamSynchronize(st0);               // the host arrays are freed next
     cleanup();
     if (e != hipSuccess) { rc = sfail(e, "gf_sampler_create_multi"); gf_sampler_destroy(s); return rc; }
     *out = s;
@@ -647,8 +656,9 @@ int gf_sampler_reset(gf_sampler* s)
     gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device);
     GFS_HIP(hipSetDevice(device));
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
-    GFS_HIP(hipMemset(s->d_naccept, 0, sizeof(uint32_t) * (size_t)s->nchains * s->nwalkers));
-    GFS_HIP(hipMemset(s->d_flags, 0, sizeof(uint32_t) * 4));
+    GFS_HIP(hipMemsetAsync(s->d_naccept, 0, sizeof(uint32_t) * (size_t)s->nchains * s->nwalkers, (hipStream_t)stream));
+    GFS_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(uint32_t) * 4, (hipStream_t)stream));
+    GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
     s->nstored = 0;
     s->steps_since_reset = 0;
     return GF_OK;
@@ -680,11 +690,12 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             if (s->nstored > 0) {
                 // every chain's stored prefix in one strided copy: row = chain, pitch = old / new chain stride
                 const size_t row = sizeof(double) * s->nwalkers * s->ndim, lrow = sizeof(double) * s->nwalkers;
-                hipError_t e_ = hipMemcpy2D(nc, row * cap, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
-                                            hipMemcpyDeviceToDevice);
+                hipError_t e_ = hipMemcpy2DAsync(nc, row * cap, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
+                                                 hipMemcpyDeviceToDevice, st);
                 if (e_ == hipSuccess)
-                    e_ = hipMemcpy2D(nl, lrow * cap, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored, s->nchains,
-                                     hipMemcpyDeviceToDevice);
+                    e_ = hipMemcpy2DAsync(nl, lrow * cap, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored, s->nchains,
+                                          hipMemcpyDeviceToDevice, st);
+                if (e_ == hipSuccess) e_ = hipStreamSynchronize(st);                  // the old buffers are freed next
                 if (e_ != hipSuccess) { (void)hipFree(nc); (void)hipFree(nl); return sfail(e_, "chain repack"); }
             }
             if (s->d_chain) (void)hipFree(s->d_chain);
@@ -693,11 +704,11 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         }
     }
     // device-side step counters for this run
-    StepState hs;
+    StepState& hs = s->h_state;                   // member: outlives the asynchronous upload
     hs.iteration_base = s->iteration; hs.run_step_base = 0; hs.store_base = s->nstored;
     hs.store = store ? 1 : 0; hs.thin = thin;
     GFS_HIP(hipStreamSynchronize(st));          // earlier runs must be done with the counters
-    GFS_HIP(hipMemcpy(s->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    GFS_HIP(hipMemcpyAsync(s->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     StretchArgs a;
     a.state = s->d_state;
     a.pos = s->d_pos; a.lnp = s->d_lnp; a.naccept = s->d_naccept; a.flags = s->d_flags;
@@ -813,8 +824,12 @@ int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob)
     int rc = gf_model_sync(s->model);
     if (rc != GF_OK) return rc;
     const size_t nw = (size_t)s->nchains * s->nwalkers;
-    if (pos) GFS_HIP(hipMemcpy(pos, s->d_pos, sizeof(double) * nw * s->ndim, hipMemcpyDeviceToHost));
-    if (lnprob) GFS_HIP(hipMemcpy(lnprob, s->d_lnp, sizeof(double) * nw, hipMemcpyDeviceToHost));
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (pos) GFS_HIP(hipMemcpyAsync(pos, s->d_pos, sizeof(double) * nw * s->ndim, hipMemcpyDeviceToHost, st));
+    if (lnprob) GFS_HIP(hipMemcpyAsync(lnprob, s->d_lnp, sizeof(double) * nw, hipMemcpyDeviceToHost, st));
+    GFS_HIP(hipStreamSynchronize(st));
     return GF_OK;
 }
 
@@ -823,21 +838,24 @@ int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob)
 int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary)
 {
     if (!s) return GF_ERR_INVALID_ARG;
-    int rc = gf_model_sync(s->model);
-    if (rc != GF_OK) return rc;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;                 // in order behind the sampler's launches
     const size_t per = (size_t)s->nwalkers;
     if (s->nstored > 0) {
         // one strided copy per array: row = chain (stored prefix), device pitch = capacity stride
         const size_t row = sizeof(double) * per * s->ndim, lrow = sizeof(double) * per;
         if (chain)
-            GFS_HIP(hipMemcpy2D(chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
-                                hipMemcpyDeviceToHost));
+            GFS_HIP(hipMemcpy2DAsync(chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
+                                     hipMemcpyDeviceToHost, st));
         if (lnprob_chain)
-            GFS_HIP(hipMemcpy2D(lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored,
-                                s->nchains, hipMemcpyDeviceToHost));
+            GFS_HIP(hipMemcpy2DAsync(lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored,
+                                     s->nchains, hipMemcpyDeviceToHost, st));
     }
-    if (naccepted) GFS_HIP(hipMemcpy(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost));
-    if (nonunitary) GFS_HIP(hipMemcpy(nonunitary, s->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (naccepted)
+        GFS_HIP(hipMemcpyAsync(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost, st));
+    if (nonunitary) GFS_HIP(hipMemcpyAsync(nonunitary, s->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GFS_HIP(hipStreamSynchronize(st));
     return GF_OK;
 }
 

@@ -283,3 +283,43 @@ def test_handles_are_independent_across_threads(golden):
     assert not errors, errors
     for m in models:
         m.close()
+
+
+def test_bsm_samplers_capture_graphs_concurrently():
+    """Two BSM samplers (per-half-step launches replayed from hipGraphs, thread-local capture) advanced from two
+    host threads at once reproduce their single-threaded chains."""
+    import threading
+    asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
+    fs = [llh_utils.bsm_ln_prob(bsm_args(6, tex, (0., 1., 0.)), asimov, ps, smearing=0.3, on_nonunitary="-inf")
+          for tex in (Texture.OET, Texture.OUT)]
+    rng = np.random.default_rng(3)
+    box = np.array(ps.seeds, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(64, 12))
+    p0[:, 11] = rng.uniform(-52, -44, 64)
+
+    def chain_of(f, k):
+        s = mcmc_utils.DeviceEnsembleSampler(64, 12, f, seed=k)
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 70)                                    # 64 steps from the graph + 6 eager
+        c = s.chain
+        s.close()
+        return c
+    want = [chain_of(f, k) for k, f in enumerate(fs)]
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = chain_of(fs[k], k)
+        except Exception as exc:       # noqa: BLE001
+            errors.append((k, repr(exc)))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for k in range(2):
+        assert np.array_equal(got[k], want[k])
+    for f in fs:
+        f.close()
