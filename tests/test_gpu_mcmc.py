@@ -323,3 +323,59 @@ def test_bsm_samplers_capture_graphs_concurrently():
         assert np.array_equal(got[k], want[k])
     for f in fs:
         f.close()
+
+
+def test_graph_capture_survives_allocation_traffic_from_another_thread(golden):
+    """While one thread's BSM sampler captures and replays graphs, another thread creates and destroys models and
+    grows its staging buffers (hipMalloc / hipFree / hipHostMalloc / hipHostFree): neither may disturb the other."""
+    import threading
+    asimov12, ps12 = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
+    f = llh_utils.bsm_ln_prob(bsm_args(6, Texture.OET, (0., 1., 0.)), asimov12, ps12, smearing=0.3, on_nonunitary="-inf")
+    rng = np.random.default_rng(3)
+    box = np.array(ps12.seeds, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(64, 12))
+    p0[:, 11] = rng.uniform(-52, -44, 64)
+
+    def chain():
+        s = mcmc_utils.DeviceEnsembleSampler(64, 12, f, seed=1)
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 70)
+        c = s.chain
+        s.close()
+        return c
+    want = chain()
+    asimov, ps = notebook_sets(golden)
+    th = np.ascontiguousarray(golden["g6_theta"][:5000])
+    ref = golden["g6_lnprob"][:5000]
+    errors, stop = [], threading.Event()
+
+    def sampler_thread():
+        try:
+            for _ in range(6):
+                assert np.array_equal(chain(), want)
+        except Exception as exc:       # noqa: BLE001
+            errors.append(("sampler", repr(exc)))
+        finally:
+            stop.set()
+
+    def churn_thread():
+        try:
+            k = 0
+            while not stop.is_set() and k < 400:
+                g = llh_utils.notebook_ln_prob(asimov, ps)
+                for n in (10, 3000, 100, 5000):                 # staging grows twice per model
+                    got = g.model.lnprob(th[:n], want_status=False)
+                    fin = np.isfinite(ref[:n])
+                    assert np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], ref[:n][fin], rtol=1e-10)
+                g.close()
+                k += 1
+        except Exception as exc:       # noqa: BLE001
+            errors.append(("churn", repr(exc)))
+
+    ts = [threading.Thread(target=sampler_thread), threading.Thread(target=churn_thread)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=180)
+    assert not errors, errors
+    f.close()
