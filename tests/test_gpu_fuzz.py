@@ -68,6 +68,8 @@ def _theta(ps, n, rng):
     th[out, cols[out]] = box[cols[out], 1] + 0.3
     edge = rng.random(n) < 0.02                                      # and some sit exactly on a boundary (closed box)
     th[edge, cols[edge]] = box[cols[edge], rng.integers(0, 2, edge.sum())]
+    wild = rng.random(n) < 0.01                                      # NaN / +-inf coordinates: -inf like the reference
+    th[wild, cols[wild]] = rng.choice([np.nan, np.inf, -np.inf], wild.sum())
     return th
 
 
