@@ -140,10 +140,13 @@ def test_random_bsm_configurations(oracle, seed):
     th = rng.uniform(box[:, 0], box[:, 1], size=(n, len(ps)))
     lo, hi = Cf.SCALE_BOUNDARIES[dim]
     th[:, -1] = rng.uniform(lo, lo + rng.uniform(0.3, 1.0) * (hi - lo), n)
+    wild = rng.random(n) < 0.01                                      # NaN / +-inf coordinates: out of prior, -inf
+    th[wild, rng.integers(0, len(ps), wild.sum())] = rng.choice([np.nan, np.inf, -np.inf], wild.sum())
     ref, ref_fr, ref_st = oracle.lnprob_batch(om, th, want_fr=True, want_status=True)
     with Model(compile_model(ps, "BSM_GAUSS", **kw)) as m:
         lp, fr, st = m.lnprob(th, want_fr=True)
         pfr, pst = m.propagate(th)
+    assert np.all(st[wild] == _lib.GF_ST_OUT_OF_PRIOR) and np.all(ref_st[wild] == 1) and np.all(np.isneginf(lp[wild]))
     r80 = oracle.unitarity_residual_batch(om, th)
     inbox = (st != _lib.GF_ST_OUT_OF_PRIOR) & (ref_st != 1)
     clear = ((r80 < 1e-9) | (r80 > 1e-5)) & inbox
