@@ -65,6 +65,7 @@ SIGNATURES = {
     "gf_model_destroy": (None, [_vp]),
     "gf_model_ndim": (C.c_int, [_vp]),
     "gf_lnprob_batch": (C.c_int, [_vp, _dp, C.c_int64, _dp, _dp, _ip]),
+    "gf_lnprob_cube_batch": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, _ip, _dp, _dp, _dp, _ip]),
     "gf_propagate_batch": (C.c_int, [_vp, _dp, C.c_int64, _dp, _ip]),
     "gf_haar_draw": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, _dp, _dp]),
     "gf_device_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),

@@ -78,6 +78,8 @@ struct gf_model {
     int32_t* d_status = nullptr;
     void* h_pin = nullptr;       // pinned mirror: theta | lnprob | fr | status
     size_t h_pin_bytes = 0;
+    double* d_cube = nullptr;    // gf_lnprob_cube_batch: the unit-cube rows on the device
+    size_t cube_cap = 0;
 };
 
 namespace {
@@ -455,6 +457,7 @@ void gf_model_destroy(gf_model* m)
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_status) (void)hipFree(m->d_status);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
+    if (m->d_cube) (void)hipFree(m->d_cube);
     delete m;
 }
 
@@ -548,6 +551,53 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
 int gf_lnprob_batch(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status)
 {
     return run_host(m, theta, n, lnprob, fr, status, true);
+}
+
+// MultiNest-style batch (golemflavor/mn.py:26-45 lnProb): cube [n][nscan] in the unit cube; column cols[k] of theta is
+// lo + (hi - lo) * cube[.][k] with the model's own box for that column, every other column is base[col].  The map runs
+// on the device; only the cube crosses PCIe.
+int gf_lnprob_cube_batch(gf_model* m, const double* cube, int64_t n, int nscan, const int32_t* cols, const double* base,
+                         double* lnprob, double* fr, int32_t* status)
+{
+    if (!m || n < 0 || nscan < 1 || nscan > m->c.ndim || !cols || !base || (n > 0 && (!cube || !lnprob))) return GF_ERR_INVALID_ARG;
+    bool seen[GF_MAX_DIM] = {false};
+    for (int k = 0; k < nscan; ++k) {
+        if (cols[k] < 0 || cols[k] >= m->c.ndim || seen[cols[k]]) return GF_ERR_INVALID_ARG;
+        seen[cols[k]] = true;
+    }
+    if (n == 0) return GF_OK;
+    GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
+    int rc = ensure_staging(m, n);
+    if (rc != GF_OK) return rc;
+    const size_t nd = (size_t)m->c.ndim;
+    double* h_cube = (double*)m->h_pin;                      // the theta slot of the pinned mirror holds the (smaller) cube
+    double* h_out = h_cube + nd * m->cap;
+    double* h_fr = h_out + m->cap;
+    int32_t* h_st = (int32_t*)(h_fr + 3 * m->cap);
+    double* d_ln = m->d_out;
+    double* d_fr = m->d_out + m->cap;
+    // device side: the cube rows get their own buffer, grown on demand (d_theta receives the expanded rows)
+    if ((int64_t)m->cube_cap < n * nscan) {
+        if (m->d_cube) (void)hipFree(m->d_cube);
+        m->d_cube = nullptr; m->cube_cap = 0;
+        GF_HIP(hipMalloc((void**)&m->d_cube, sizeof(double) * (size_t)n * nscan));
+        m->cube_cap = (size_t)n * nscan;
+    }
+    std::memcpy(h_cube, cube, sizeof(double) * (size_t)n * nscan);
+    GF_HIP(hipMemcpyAsync(m->d_cube, h_cube, sizeof(double) * (size_t)n * nscan, hipMemcpyHostToDevice, m->stream));
+    hipError_t e = gf_launch_cube_to_theta(m->c, nscan, cols, base, m->d_cube, n, m->d_theta, m->cus, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "cube map launch");
+    rc = launch_lnprob(m, m->stream, m->d_theta, GF_LAYOUT_AOS, n, d_ln, fr ? d_fr : nullptr, status ? m->d_status : nullptr);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipMemcpyAsync(h_out, d_ln, sizeof(double) * n, hipMemcpyDeviceToHost, m->stream));
+    if (fr) GF_HIP(hipMemcpyAsync(h_fr, d_fr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, m->stream));
+    if (status) GF_HIP(hipMemcpyAsync(h_st, m->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+    GF_HIP(hipStreamSynchronize(m->stream));
+    std::memcpy(lnprob, h_out, sizeof(double) * n);
+    if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
+    if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
+    return GF_OK;
 }
 
 int gf_propagate_batch(gf_model* m, const double* theta, int64_t n, double* fr, int32_t* status)

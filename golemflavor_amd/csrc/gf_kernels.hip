@@ -291,6 +291,27 @@ __global__ __launch_bounds__(GF_BLOCK) void k_flavor_hist(const double* __restri
     }
 }
 
+// MultiNest's unit cube -> theta (golemflavor/mn.py:33-39): the scanned columns are mapped onto their ranges,
+// theta_c = lo_c + (hi_c - lo_c) u, every other column keeps its current value.  One thread per (walker, column).
+struct CubeMap {
+    int32_t ndim, nscan;
+    int32_t slot[GF_MAX_DIM];       // column -> index into the cube row, or -1
+    double lo[GF_MAX_DIM], span[GF_MAX_DIM], base[GF_MAX_DIM];
+};
+
+__global__ __launch_bounds__(GF_BLOCK) void k_cube_to_theta(const CubeMap cm, const double* __restrict__ cube, int64_t n,
+                                                            double* __restrict__ theta)
+{
+    const int64_t total = n * cm.ndim;
+    for (int64_t i = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GF_BLOCK) {
+        const int64_t w = i / cm.ndim;
+        const int col = (int)(i - w * cm.ndim);
+        const int sl = cm.slot[col];
+        // product, then sum, each rounded (mn.py:36 is a Python expression): no fused multiply-add here
+        theta[i] = sl >= 0 ? __dadd_rn(__dmul_rn(cm.span[col], cube[w * cm.nscan + sl]), cm.lo[col]) : cm.base[col];
+    }
+}
+
 #ifndef GF_BLOCKS_PER_CU
 #define GF_BLOCKS_PER_CU 8
 #endif
@@ -398,6 +419,22 @@ hipError_t gf_launch_lnprob_sm(const GfCommon& c, const double* ptab, const doub
     case 12: return launch_lnprob_sm_n<12>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
     default: return launch_lnprob_sm_n<0>(c, ptab, theta, layout, n, lnprob, fr, status, cus, s);
     }
+}
+
+hipError_t gf_launch_cube_to_theta(const GfCommon& c, int nscan, const int32_t* cols, const double* base, const double* cube,
+                                   int64_t n, double* theta, int cus, hipStream_t s)
+{
+    CubeMap cm;
+    cm.ndim = c.ndim; cm.nscan = nscan;
+    for (int d = 0; d < GF_MAX_DIM; ++d) { cm.slot[d] = -1; cm.lo[d] = 0.0; cm.span[d] = 0.0; cm.base[d] = d < c.ndim ? base[d] : 0.0; }
+    for (int k = 0; k < nscan; ++k) {
+        cm.slot[cols[k]] = k;
+        cm.lo[cols[k]] = c.lo[cols[k]];
+        cm.span[cols[k]] = c.hi[cols[k]] - c.lo[cols[k]];            // mn.py:36 (hi - lo) * cube + lo
+    }
+    const int grid = grid_for(n * c.ndim, GF_BLOCK, cus);
+    hipLaunchKernelGGL(k_cube_to_theta, dim3(grid), dim3(GF_BLOCK), 0, s, cm, cube, n, theta);
+    return hipGetLastError();
 }
 
 hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int layout, int64_t n, double* fr,

@@ -167,9 +167,11 @@ class CubeLnProb:
 
     `mn_paramset` is the scanned subset of `llh_paramset`; the unit cube is mapped onto its ranges,
     theta_i = (hi_i - lo_i) * cube_i + lo_i (mn.py:35-36), the other columns keep their current
-    `.value`, and the batch goes to the GPU in one launch: a nested sampler can hand over all its
+    `.value`, and the batch goes to the GPU in one call: a nested sampler can hand over all its
     live-point proposals at once (`cube` of shape (n, ndim)) or one point (shape (ndim,)), as
-    MultiNest does.
+    MultiNest does.  When `ln_prob` is a device posterior (`LnProb`) whose box for the scanned columns is the
+    scanned ranges -- the reference's case: mn_paramset holds the same Param objects -- the map itself runs on
+    the device (`gf_lnprob_cube_batch`) and only the cube crosses PCIe; otherwise it is one numpy expression.
     """
 
     def __init__(self, ln_prob, mn_paramset, llh_paramset):
@@ -180,6 +182,10 @@ class CubeLnProb:
         self.lo, self.span = rng[:, 0], rng[:, 1] - rng[:, 0]
         self.base = np.array(llh_paramset.values, dtype=np.float64)
         self.ndim = len(self.cols)
+        model = getattr(ln_prob, "model", None)
+        box = np.array(llh_paramset.ranges, dtype=np.float64)[self.cols]
+        self.on_device = (isinstance(ln_prob, LnProb) and model is not None and model.ndim == len(names)
+                          and np.array_equal(box, rng))
 
     def __call__(self, cube, ndim=None, n_params=None):
         if ndim is not None and ndim != self.ndim:
@@ -188,6 +194,17 @@ class CubeLnProb:
             isinstance(cube, np.ndarray) else np.asarray(cube, dtype=np.float64)
         single = u.ndim == 1
         u = np.atleast_2d(u)[:, :self.ndim]
+        if self.on_device:
+            f = self.ln_prob
+            lp, st = f.model.lnprob_cube(u, self.cols, self.base)
+            bad = st == _lib.GF_ST_NON_UNITARY
+            if f.check_unitarity and bad.any():
+                if f.on_nonunitary == "raise":
+                    raise AssertionError("Matrix is not unitary!")
+                lp = np.where(bad, -np.inf, lp)
+            f.ncalls += 1
+            f.nevals += lp.shape[0]
+            return float(lp[0]) if single else lp
         theta = np.tile(self.base, (u.shape[0], 1))
         theta[:, self.cols] = self.span * u + self.lo
         out = self.ln_prob(theta)

@@ -114,6 +114,22 @@ class Model:
             res += (st,)
         return res if len(res) > 1 else out
 
+    def lnprob_cube(self, cube, cols, base, want_status=True):
+        """MultiNest-style batch (mn.py:26-45): cube (n, nscan) in the unit cube -> lnprob (n,) [, status]; column
+        cols[k] is mapped onto the model's own box on the device, the other columns take base[col]."""
+        u = np.ascontiguousarray(np.atleast_2d(np.asarray(cube, dtype=np.float64)))
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        base = np.ascontiguousarray(base, dtype=np.float64)
+        if u.shape[1] != len(cols) or base.shape != (self.ndim,):
+            raise AssertionError("Length of MultiNest scan paramset is not the same as the input params")
+        n = u.shape[0]
+        out = np.empty(n, dtype=np.float64)
+        st = np.empty(n, dtype=np.int32) if want_status else None
+        check(self._L.gf_lnprob_cube_batch(self._h, u.ctypes.data_as(_lib._dp), n, len(cols), cols.ctypes.data_as(_lib._ip),
+                                           base.ctypes.data_as(_lib._dp), out.ctypes.data_as(_lib._dp), None,
+                                           st.ctypes.data_as(_lib._ip) if want_status else None), "gf_lnprob_cube_batch")
+        return (out, st) if want_status else out
+
     def propagate(self, theta, want_status=True):
         """theta (n, ndim) -> measured composition (n, 3) [, status]."""
         th = _as_theta(theta, self.ndim)

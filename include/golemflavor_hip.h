@@ -135,6 +135,12 @@ int gf_model_ndim(const gf_model* m);
 int gf_lnprob_batch(gf_model* m, const double* theta, int64_t n,
                     double* lnprob, double* fr, int32_t* status);
 
+/* MultiNest-style batch, golemflavor/mn.py:26-45 lnProb(cube, ndim, n_params, ...): cube [n][nscan] lies in the unit
+ * cube; column cols[k] of theta is lo + (hi - lo) * cube[.][k] (the model's own box of that column, mn.py:35-36), every
+ * other column is base[col] (the paramset's current value, mn.py:37-39); then ln_prob.  The map runs on the device. */
+int gf_lnprob_cube_batch(gf_model* m, const double* cube, int64_t n, int nscan, const int32_t* cols, const double* base,
+                         double* lnprob, double* fr, int32_t* status);
+
 /* fr[i] = measured flavor composition for theta[i]: chain post-processing of
  * scripts/mc_unitary.py:189-193 (u_to_fr(source_ratio, angles_to_u(x))) and
  * scripts/mc_texture.py:216-221 (flux_averaged_BSMu).  No priors, no likelihood. */

@@ -413,10 +413,36 @@ def test_multinest_style_cube_adapter(golden):
     out = g(cube)
     lo = np.array(mn_ps.ranges)[:, 0]; hi = np.array(mn_ps.ranges)[:, 1]
     theta = np.column_stack([(hi - lo) * cube + lo, np.full(50, -50.0)])
-    assert np.array_equal(out, f(theta))
+    assert g.on_device                                             # the map ran in gf_lnprob_cube_batch ...
+    assert np.array_equal(out, f(theta))                           # ... and is bitwise mn.py:36's expression
     assert g(list(cube[3]), 11, 11) == out[3]
     with pytest.raises(AssertionError):
         g(cube[0], 10, 10)
+    # a scanned subset in another column order, and a wider scan box than the model's (host map then)
+    sub = ParamSet([ps["astroNorm"], ps["s_23_2"], ps["dcp"]])
+    g2 = llh_utils.CubeLnProb(f, sub, ps)
+    assert g2.on_device
+    c2 = rng.uniform(0.2, 0.8, size=(300, 3))
+    th2 = np.tile(np.array(ps.values, dtype=float), (300, 1))
+    for k, name in enumerate(["astroNorm", "s_23_2", "dcp"]):
+        r = ps[name].ranges
+        th2[:, list(ps.names).index(name)] = (r[1] - r[0]) * c2[:, k] + r[0]
+    assert np.array_equal(g2(c2), f(th2), equal_nan=True)
+    from golemflavor_amd.param import Param
+    wide = ParamSet([Param(name="dcp", value=1.0, ranges=[0., 3.0], tag=ps["dcp"].tag)])
+    g3 = llh_utils.CubeLnProb(f, wide, ps)
+    assert not g3.on_device
+    th3 = np.tile(np.array(ps.values, dtype=float), (20, 1))
+    th3[:, 3] = 3.0 * c2[:20, 0]
+    assert np.array_equal(g3(c2[:20, :1]), f(th3), equal_nan=True)
+    # argument checks of the C entry point
+    L = _lib.lib()
+    import ctypes as C
+    cols = (C.c_int32 * 2)(3, 3)
+    base = np.array(ps.values, dtype=float)
+    outb = np.empty(4)
+    assert L.gf_lnprob_cube_batch(f.model._h, c2.ctypes.data_as(_lib._dp), 4, 2, cols, base.ctypes.data_as(_lib._dp),
+                                  outb.ctypes.data_as(_lib._dp), None, None) == _lib.GF_ERR_INVALID_ARG   # duplicate column
     f.close()
 
 
