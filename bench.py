@@ -47,8 +47,8 @@ BYTES_PER_EVAL = 6 * 8 + 8     # 8*ndim read + 8 written, no fr 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--walkers", type=int, default=4096, help="walkers per ensemble (BASELINE config 2)")
     ap.add_argument("--ensembles", type=int, default=4096, help="independent ensembles stacked per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
