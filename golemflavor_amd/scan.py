@@ -158,6 +158,19 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25):
     return out
 
 
+def point_filename(config, point, a):
+    """File stem of one grid point's chain: the reference's `mc_texture` + gen_identifier (scripts/mc_texture.py:184,
+    misc.py:44-51: `_DIM{d}_sfr_{source}[_{texture}]`), plus the scale, which the reference's identifier lacks
+    because its jobs do not scan it."""
+    if config == "C4":
+        scale, source = point
+        ns = argparse.Namespace(dimension=a.dimension, source_ratio=source, texture=Texture[a.texture])
+        return "mc_texture%s_logLam%+.3f" % (mcmc_utils.chain_identifier(ns), scale)
+    dim, tex, source, scale = point
+    ns = argparse.Namespace(dimension=dim, source_ratio=source, texture=tex)
+    return "fr%s_logLam%+.3f" % (mcmc_utils.chain_identifier(ns), scale)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--config", choices=["C4", "C5"], default="C4")
@@ -169,6 +182,9 @@ def main(argv=None):
     ap.add_argument("--texture", default="OET")
     ap.add_argument("--outfile", default=None, help="np.save the gathered chains here (rank 0)")
     ap.add_argument("--no-stack", action="store_true", help="one sampler per grid point on its own stream (A/B)")
+    ap.add_argument("--datadir", default=None,
+                    help="write one .npy per grid point, named as the reference's jobs name theirs "
+                         "(scripts/mc_texture.py:184, misc.py:44-51), each rank its own points")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,6 +211,10 @@ def main(argv=None):
         evals_per_point = nw * (a.burnin + a.nsteps)
     mine = gdist.shard(len(pts), backend.rank, backend.world)
     local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=not a.no_stack)
+    if a.datadir:
+        # the reference's jobs each save their own chain to the shared filesystem; so does every rank here
+        for g in mine:
+            mcmc_utils.save_chains(local[g], os.path.join(a.datadir, point_filename(a.config, pts[g], a)))
     t1 = time.perf_counter()
     # chain blocks travel over RCCL / xGMI (device all-gather through the library's own communicator); gloo is
     # the fallback when the communicator cannot be set up, and the control plane either way

@@ -1,5 +1,6 @@
 """GPU: the emcee-driven call surface end to end (BASELINE config 1 plumbing) and the RCCL binding."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -98,6 +99,22 @@ def test_grid_scans_c4_c5_smoke(capsys):
     scan.main(["--config", "C5", "--points", "2", "--nwalkers", "32", "--burnin", "5", "--nsteps", "10"])
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0 and out["gather"] == "local"
+
+
+def test_grid_scan_writes_reference_named_files(capsys, tmp_path):
+    """--datadir: one .npy per grid point under the reference's naming scheme (misc.py:44-51)."""
+    import json
+    from golemflavor_amd import scan
+    scan.main(["--config", "C4", "--points", "3", "--nwalkers", "32", "--burnin", "5", "--nsteps", "10",
+               "--datadir", str(tmp_path / "chains"), "--outfile", str(tmp_path / "all")])
+    capsys.readouterr()
+    files = sorted(os.listdir(str(tmp_path / "chains")))
+    assert files == ["mc_texture_DIM6_sfr_0.14_0.86_0.00_OET_logLam-56.000.npy", "mc_texture_DIM6_sfr_0.29_0.71_0.00_OET_logLam-56.000.npy",
+                     "mc_texture_DIM6_sfr_0_1_0_OET_logLam-56.000.npy"], files
+    allc = np.load(str(tmp_path / "all.npy"))
+    lo = Cf.SCALE_BOUNDARIES[6][0]
+    first = np.load(str(tmp_path / "chains" / ("mc_texture_DIM6_sfr_0_1_0_OET_logLam%+.3f.npy" % lo)))
+    assert first.shape == (320, 9) and np.array_equal(first, allc[0], equal_nan=True)
 
 
 def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
