@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "gf_consts.h"
 #include "gf_launch.h"
 #include "gf_device.hpp"
@@ -37,13 +39,18 @@ using namespace gfdev;
 #ifndef GF_BSM_WAVES
 #define GF_BSM_WAVES 2
 #endif
-template <int NDIM, bool WITH_LLH, bool CHECK_UNI>
+// LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
+// SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
+// walkers per tile.  Results are bitwise those of LPW = 1.
+template <int NDIM, bool WITH_LLH, bool CHECK_UNI, int LPW>
 __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
                                                       int32_t* __restrict__ status)
 {
+    constexpr int WPT = GF_WAVE / LPW;                                  // walkers per wave tile
+    extern __shared__ __attribute__((aligned(16))) double fdyn[];        // LPW > 1: per lane group [nbins][3] + [LPW]
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
     __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
     double* ttab = ctab + GF_MAX_DIM * 4;       // texture projector entries, see flux_average
@@ -60,15 +67,18 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int wave = threadIdx.x / GF_WAVE;
     const int ndim = NDIM ? NDIM : c.ndim;
+    const int sub = LPW > 1 ? lane % LPW : 0;
+    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * (3 * tb->nbins + LPW) : nullptr;
     double* tile = tiles[wave];
-    const int64_t ntiles = (n + GF_WAVE - 1) / GF_WAVE;
+    const int64_t ntiles = (n + WPT - 1) / WPT;
     const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
-        const int64_t w0 = t * GF_WAVE;
-        stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane);
-        const int64_t i = w0 + lane;
+        const int64_t w0 = t * WPT;
+        const int64_t nend = (LPW > 1 && w0 + WPT < n) ? w0 + WPT : n;     // stage this tile's WPT rows only
+        stage_theta<NDIM>(theta, layout, nend, w0, ndim, tile, lane);
+        const int64_t i = w0 + lane / LPW;
         if (i < n) {
-            const double* row = tile + lane * ndim;
+            const double* row = tile + (lane / LPW) * ndim;
             double lp = 0.0;
             bool inbox = true;
             if (WITH_LLH) inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
                 double residual = 0.0;
-                flux_average<CHECK_UNI>(c, tb, ttab, row, fr, residual);
+                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, residual, sub, fgrp);
                 st = ST_OK;
                 if (CHECK_UNI && !(residual < UNI_THRESHOLD)) st = ST_NON_UNITARY;
                 if (WITH_LLH) {
@@ -90,9 +100,11 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
                 }
                 if (st == ST_NON_UNITARY) val = gf_nan();              // the reference raises here
             }
-            if (WITH_LLH) lnprob[i] = val;
-            if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
-            if (status) status[i] = st;
+            if (sub == 0) {
+                if (WITH_LLH) lnprob[i] = val;
+                if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
+                if (status) status[i] = st;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -108,27 +120,57 @@ inline int grid_for(int64_t work_items, int per_block, int cus)
     return (int)blocks;
 }
 
-template <int NDIM>
-hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, const double* ptab, const double* theta, int layout, int64_t n,
-                    int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+// Lanes per walker for a batch of n walkers, from a sweep on MI355X (profiles/r01/bsm_lanes_per_walker_sweep.txt:
+// 12-column posterior, 20 bins; 16 lanes win up to 4096 walkers, 4 lanes up to 32768, one lane beyond): the widest split
+// whose waves still fit one (16 lanes) or two (4 lanes) per SIMD -- past that the repeated per-walker prologue costs
+// more than the shorter critical path saves.
+inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 {
-    const int grid = grid_for(n, GF_BLOCK, cus);
+    (void)check;
+    const char* force = std::getenv("GF_BSM_LPW");                       // diagnostics / A-B
+    if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
+    if (nbins < 2) return 1;
+    const int64_t simds = 4 * (int64_t)(cus > 0 ? cus : 256);
+    const int64_t waves1 = (n + GF_WAVE - 1) / GF_WAVE;
+    auto fits = [&](int lpw) { return (size_t)(GF_BLOCK / lpw) * (3 * nbins + lpw) * sizeof(double) <= 32 * 1024; };
+    if (waves1 * 16 <= simds && fits(16)) return 16;
+    if (waves1 * 4 <= 2 * simds && fits(4)) return 4;
+    return 1;
+}
+
+template <int NDIM, int LPW>
+hipError_t launch_nl(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
+                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+{
+    const int grid = grid_for(n * LPW, GF_BLOCK, cus);
+    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * (3 * nbins + LPW) * sizeof(double) : 0;
     const bool chk = status != nullptr;
-#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU>), dim3(grid), dim3(GF_BLOCK), 0, s, c, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
+#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, c, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
     if (with_llh) { if (chk) GF_GO(true, true); else GF_GO(true, false); }
     else          { if (chk) GF_GO(false, true); else GF_GO(false, false); }
 #undef GF_GO
     return hipGetLastError();
 }
 
+template <int NDIM>
+hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
+                    int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+{
+    switch (lanes_for(n, nbins, cus, status != nullptr)) {
+    case 4: return launch_nl<NDIM, 4>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 16: return launch_nl<NDIM, 16>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    default: return launch_nl<NDIM, 1>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    }
+}
+
 }  // namespace
 
-hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, const double* ptab, const double* theta, int layout,
+hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 12: return launch_n<12>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_n<0>(c, d_bsm, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 7: return launch_n<7>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 12: return launch_n<12>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    default: return launch_n<0>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
     }
 }

@@ -202,7 +202,7 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
@@ -214,7 +214,7 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
+        e = gf_launch_bsm(m->c, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");
