@@ -43,12 +43,16 @@ using namespace gfdev;
 // SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
 // walkers per tile.  Results are bitwise those of LPW = 1.
 template <int NDIM, bool WITH_LLH, bool CHECK_UNI, int LPW>
-__global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(const GfCommon c, const GfBsm* __restrict__ tb,
+__global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
                                                       int32_t* __restrict__ status)
 {
+    // the constants by pointer (the model's device block), not by value: as a 848-B kernel argument the compiler loads
+    // every field up front and spills ~100 scalar registers to VGPR lanes around the tile loop (356 v_readlane /
+    // v_writelane per tile in the by-value build)
+    const GfCommon& c = *cp;
     constexpr int WPT = GF_WAVE / LPW;                                  // walkers per wave tile
     extern __shared__ __attribute__((aligned(16))) double fdyn[];        // LPW > 1: per lane group [nbins][3] + [LPW]
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
@@ -139,13 +143,13 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 }
 
 template <int NDIM, int LPW>
-hipError_t launch_nl(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
+hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                      int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     const int grid = grid_for(n * LPW, GF_BLOCK, cus);
     const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * (3 * nbins + LPW) * sizeof(double) : 0;
     const bool chk = status != nullptr;
-#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, c, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
+#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
     if (with_llh) { if (chk) GF_GO(true, true); else GF_GO(true, false); }
     else          { if (chk) GF_GO(false, true); else GF_GO(false, false); }
 #undef GF_GO
@@ -153,24 +157,24 @@ hipError_t launch_nl(const GfCommon& c, const GfBsm* d_bsm, int nbins, const dou
 }
 
 template <int NDIM>
-hipError_t launch_n(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
+hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
                     int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     switch (lanes_for(n, nbins, cus, status != nullptr)) {
-    case 4: return launch_nl<NDIM, 4>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 16: return launch_nl<NDIM, 16>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_nl<NDIM, 1>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
     }
 }
 
 }  // namespace
 
-hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
+hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 12: return launch_n<12>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_n<0>(c, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
     }
 }

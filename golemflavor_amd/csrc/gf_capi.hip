@@ -66,6 +66,7 @@ struct gf_model {
     GfBsm hb;
     void* d_block = nullptr;     // the model's constant block (from the per-device pool): d_ptab | d_bsm
     GfBsm* d_bsm = nullptr;
+    GfCommon* d_common = nullptr;  // device copy of `c` (same block)
     double* d_ptab = nullptr;    // [GF_MAX_DIM][4] = {lo, hi, loc, 1/sigma}: the kernels' LDS constant table
     hipStream_t stream = nullptr;   // created on first use (ensure_stream)
     std::mutex mu;
@@ -93,7 +94,8 @@ constexpr int POOL_MAX_DEVICES = 64;
 constexpr size_t POOL_MAX_ITEMS = 1024;
 constexpr size_t CONST_PTAB_BYTES = sizeof(double) * GF_MAX_DIM * 4;
 constexpr size_t CONST_BSM_OFFSET = (CONST_PTAB_BYTES + 255) / 256 * 256;
-constexpr size_t CONST_BLOCK_BYTES = CONST_BSM_OFFSET + sizeof(GfBsm);
+constexpr size_t CONST_COMMON_OFFSET = (CONST_BSM_OFFSET + sizeof(GfBsm) + 255) / 256 * 256;
+constexpr size_t CONST_BLOCK_BYTES = CONST_COMMON_OFFSET + sizeof(GfCommon);
 
 struct DevicePool {
     int state = 0;                 // 0 unknown, 1 gfx950, -1 something else
@@ -202,7 +204,7 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
@@ -214,7 +216,7 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
     if (n == 0) return GF_OK;
     hipError_t e;
     if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");
@@ -427,16 +429,18 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         }
         const bool bsm = d->mode == GF_MODE_BSM_GAUSS;
         if (bsm) std::memcpy(img + CONST_BSM_OFFSET, &m->hb, sizeof(GfBsm));
+        std::memcpy(img + CONST_COMMON_OFFSET, &c, sizeof(GfCommon));          // kernels that take the constants by pointer
         // stream-ordered, never the null stream: a synchronous hipMemcpy issued while another host thread is
         // capturing a sampler graph fails on this runtime and poisons that capture.  The stream comes from the
         // pool and goes straight back (the model gets its own only when an entry point needs one).
         hipStream_t up = nullptr;
         e = pool_stream(device, &up);
-        if (e == hipSuccess) e = hipMemcpyAsync(m->d_block, img, bsm ? CONST_BLOCK_BYTES : CONST_PTAB_BYTES, hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipMemcpyAsync(m->d_block, img, CONST_BLOCK_BYTES, hipMemcpyHostToDevice, up);
         if (e == hipSuccess) e = hipStreamSynchronize(up);
         if (up) pool_release(device, up, nullptr);
         m->d_ptab = reinterpret_cast<double*>(m->d_block);
         m->d_bsm = bsm ? reinterpret_cast<GfBsm*>(static_cast<unsigned char*>(m->d_block) + CONST_BSM_OFFSET) : nullptr;
+        m->d_common = reinterpret_cast<GfCommon*>(static_cast<unsigned char*>(m->d_block) + CONST_COMMON_OFFSET);
     }
     if (e != hipSuccess) {
         int rc = hip_fail(e, "gf_model_create");

@@ -14,7 +14,7 @@ hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int la
 hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,
                           int cus, hipStream_t s);
 // BSM (flux-averaged) path; `with_llh` = 0 -> composition only (propagate), 1 -> lnprob
-hipError_t gf_launch_bsm(const GfCommon& c, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
+hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s);
 hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s);
 hipError_t gf_launch_cube_to_theta(const GfCommon& c, int nscan, const int32_t* cols, const double* base, const double* cube,
