@@ -79,7 +79,7 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
     for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
         const int64_t w0 = t * WPT;
         const int64_t nend = (LPW > 1 && w0 + WPT < n) ? w0 + WPT : n;     // stage this tile's WPT rows only
-        stage_theta<NDIM>(theta, layout, nend, w0, ndim, tile, lane);
+        stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane, nend);
         const int64_t i = w0 + lane / LPW;
         if (i < n) {
             const double* row = tile + (lane / LPW) * ndim;

@@ -205,11 +205,13 @@ static __device__ __attribute__((noinline)) double pow10_cold(double x) { return
 // AoS: the block is contiguous in memory -> 16-B vector loads, lane-contiguous.
 // SoA: each lane loads its own ndim values (8-B, lane-contiguous per column).
 template <int NDIM>
+// `n` is the batch size (the SoA column stride); rows [w0, min(n_stage, w0 + 64)) are staged (n_stage < 0: n).
 __device__ __forceinline__ void stage_theta(const double* __restrict__ theta, int layout, int64_t n,
-                                            int64_t w0, int ndim_rt, double* tile, int lane)
+                                            int64_t w0, int ndim_rt, double* tile, int lane, int64_t n_stage = -1)
 {
     const int ndim = NDIM ? NDIM : ndim_rt;
-    const int64_t rows = (n - w0 < GF_WAVE) ? (n - w0) : GF_WAVE;
+    const int64_t nlim = n_stage < 0 ? n : n_stage;
+    const int64_t rows = (nlim - w0 < GF_WAVE) ? (nlim - w0) : GF_WAVE;
     if (layout == 0) {
         const int64_t count = rows * ndim;                    // doubles in this wave's span
         const double* src = theta + w0 * ndim;                // 512*ndim-byte aligned relative to theta

@@ -135,7 +135,7 @@ def test_random_bsm_configurations(oracle, seed):
     kw = dict(texture=tex, dimension=dim, binning=edges, source_ratio=src, bestfit_fr=bf, smearing=float(rng.choice([0.02, 0.2])))
     okw = dict(kw, texture=tex.name)
     om = oracle.make_model(ps, "BSM_GAUSS", **okw)
-    n = int(rng.choice([64, 700, 3000]))
+    n = int(rng.choice([64, 700, 3000, 9000]))
     box = np.array(ps.seeds, dtype=float)
     th = rng.uniform(box[:, 0], box[:, 1], size=(n, len(ps)))
     lo, hi = Cf.SCALE_BOUNDARIES[dim]
@@ -146,6 +146,14 @@ def test_random_bsm_configurations(oracle, seed):
     with Model(compile_model(ps, "BSM_GAUSS", **kw)) as m:
         lp, fr, st = m.lnprob(th, want_fr=True)
         pfr, pst = m.propagate(th)
+        # device entry point from an SoA buffer (the batch sizes here cover 16, 4 and 1 lanes per walker)
+        soa = np.ascontiguousarray(th.T)
+        d_th, d_out = m.alloc(soa.nbytes).upload(soa), m.alloc(8 * n)
+        m.lnprob_device(d_th.ptr, n, d_out.ptr, None, None, layout=GF_LAYOUT_SOA)
+        m.sync()
+        lp_soa = d_out.download((n,))
+    same = st != _lib.GF_ST_NON_UNITARY                        # (without a status array a flagged walker keeps its value)
+    assert np.array_equal(lp_soa[same], lp[same], equal_nan=True), (seed, n)
     assert np.all(st[wild] == _lib.GF_ST_OUT_OF_PRIOR) and np.all(ref_st[wild] == 1) and np.all(np.isneginf(lp[wild]))
     r80 = oracle.unitarity_residual_batch(om, th)
     inbox = (st != _lib.GF_ST_OUT_OF_PRIOR) & (ref_st != 1)
