@@ -101,6 +101,16 @@ def test_grid_scans_c4_c5_smoke(capsys):
     assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0 and out["gather"] == "local"
 
 
+def test_grid_scan_one_sampler_per_point_path(capsys):
+    """--no-stack keeps one sampler per grid point, each on its own stream (the A/B baseline of the stacked path)."""
+    import json
+    from golemflavor_amd import scan
+    for cfg, shape in (("C4", [3, 32 * 12, 9]), ("C5", [3, 32 * 12, 12])):
+        scan.main(["--config", cfg, "--points", "3", "--nwalkers", "32", "--burnin", "6", "--nsteps", "12", "--no-stack"])
+        out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert out["stacked"] is False and out["chains_shape"] == shape and out["finite_fraction"] > 0.9
+
+
 def test_grid_scan_writes_reference_named_files(capsys, tmp_path):
     """--datadir: one .npy per grid point under the reference's naming scheme (misc.py:44-51)."""
     import json
