@@ -768,7 +768,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     }
     constexpr int GRAPH_STEPS = 16;
     int64_t done = 0;
-    static const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;   // diagnostics
+    const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;          // diagnostics, read per run
     if (!no_graph && nsteps >= 2 * GRAPH_STEPS) {
         // launch-bound inner loop -> hipGraph: capture GRAPH_STEPS steps once, replay
         if (!s->graph || s->graph_chain != a.chain || s->graph_has_chain != (store ? 1 : 0)) {

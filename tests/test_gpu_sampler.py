@@ -259,6 +259,34 @@ def test_persistent_sampler_across_launch_chunks(golden, monkeypatch):
     f.close()
 
 
+def test_graph_replay_equals_eager_launches(monkeypatch):
+    """The per-half-step launches are replayed from a hipGraph in blocks of 16 steps; launching them one by one
+    (GF_SAMPLER_NO_GRAPH) must give the same chain, also across several runs with and without storing."""
+    asimov, ps = Cf.fr_paramsets(3, (0.4444444444444444, 0.0))
+    f = llh_utils.bsm_ln_prob(bsm_args(3, Texture.OUT, (1., 0., 0.)), asimov, ps, smearing=0.3, on_nonunitary="-inf")
+    rng = np.random.default_rng(4)
+    box = np.array(ps.seeds, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(2, 48, 12))
+    p0[:, :, 11] = rng.uniform(-30, -24, (2, 48))
+    out = {}
+    for eager in (False, True):
+        if eager:
+            monkeypatch.setenv("GF_SAMPLER_NO_GRAPH", "1")
+        s = mcmc_utils.DeviceEnsembleSampler(48, 12, f, nchains=2, seed=8)
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 37, storechain=False)                      # 32 from the graph + 5 eager
+        s.reset()
+        s.run_mcmc(None, 50, thin=3)                               # graph captured again: the chain pointer changed
+        s.run_mcmc(None, 40, thin=3)                               # same graph replayed
+        out[eager] = (s.chain, s.lnprobability, s.acceptance_fraction)
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_NO_GRAPH")
+    for x, y in zip(out[False], out[True]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert out[False][0].shape == (2, 48, 17 + 14, 12)
+    f.close()
+
+
 def test_device_sampler_bookkeeping_and_reset(golden):
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)
