@@ -220,3 +220,38 @@ def test_random_sampler_shapes_are_launch_shape_independent(monkeypatch, seed):
         ch, lp = out["1"][0], out["1"][1]
         again = m.lnprob(ch.reshape(-1, nd), want_status=False).reshape(lp.shape)
         assert np.array_equal(again, lp, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GF_FUZZ_SEEDS_MULTI", "6"))))
+def test_random_stacked_posteriors_follow_the_reference_stretch_move(oracle, seed):
+    """One ensemble per posterior in one sampler (random posterior structure, 2-5 posteriors differing in best fit,
+    smearing and source, random walkers / steps) against the numpy restatement of the stretch move that evaluates
+    every chain with the ORACLE on the same Philox stream."""
+    from golemflavor_amd import mcmc as mcmc_utils
+    from test_gpu_sampler import _reference_stretch
+    rng = np.random.default_rng(11000 + seed)
+    ps, mode = _random_paramset(rng)
+    nd = len(ps)
+    nmodels = int(rng.integers(2, 6))
+    kws = []
+    for _ in range(nmodels):
+        kw = dict(source_ratio=tuple(rng.dirichlet((1, 1, 1))))
+        if mode == "SM_GAUSS":
+            kw.update(bestfit_fr=tuple(rng.dirichlet((4, 3, 3))), smearing=float(rng.choice([0.1, 0.3, 0.6])))
+        kws.append(kw)
+    models = [Model(compile_model(ps, mode, **kw)) for kw in kws]
+    oms = [oracle.make_model(ps, mode, **kw) for kw in kws]
+    nwalkers = 2 * int(rng.integers(nd, nd + 12))
+    nsteps = int(rng.integers(4, 14))
+    box = np.array(ps.ranges, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nmodels, nwalkers, nd))
+    chain_seed = int(rng.integers(1, 2 ** 62))
+    s = mcmc_utils.DeviceEnsembleSampler(nwalkers, nd, models, seed=chain_seed)
+    s.run_mcmc(p0, nsteps)
+    ref_chain, ref_lnp, ref_acc = _reference_stretch(oracle, oms, p0, nsteps, chain_seed)
+    got = s.chain.transpose(0, 2, 1, 3)
+    assert np.abs(got - ref_chain).max() < 1e-11, (seed, mode, nd, nmodels, nwalkers, nsteps)
+    assert np.array_equal(np.round(s.acceptance_fraction * nsteps).astype(int), ref_acc)
+    s.close()
+    for m in models:
+        m.close()
