@@ -315,7 +315,10 @@ def main():
             with np.errstate(all="ignore"):
                 out["parity_max_rel_vs_oracle"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = value / cb["value"]
+            out["gpu_over_cpu"] = value / cb["value"]                       # vs the oracle port on this box's cores
+            refrate = cb.get("reference_python_evals_per_s_1core_build_container")
+            if refrate:                                                     # vs the reference itself (timed where it can run)
+                out["gpu_over_reference_python_1core"] = value / refrate
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 
