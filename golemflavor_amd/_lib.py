@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOLEMHIP_LIB") or os.path.join(HERE, "libgolemhip.so")   # override: kernel A/B experiments
 
-GF_ABI_VERSION = 1
+GF_ABI_VERSION = 2
 GF_MAX_DIM = 16
 GF_MAX_BINS = 64
 GF_COMM_ID_BYTES = 128
@@ -40,6 +40,7 @@ class GfModelDesc(C.Structure):
         ("dimension", C.c_int32), ("nbins", C.c_int32),
         ("idx_sm", C.c_int32 * 4), ("idx_mass", C.c_int32 * 2), ("idx_src", C.c_int32 * 2),
         ("idx_scale", C.c_int32), ("idx_mm", C.c_int32 * 4), ("idx_gamma", C.c_int32),
+        ("idx_src_x", C.c_int32), ("reserved0", C.c_int32),
         ("prior_kind", C.c_int32 * GF_MAX_DIM),
         ("lo", C.c_double * GF_MAX_DIM), ("hi", C.c_double * GF_MAX_DIM),
         ("loc", C.c_double * GF_MAX_DIM), ("sigma", C.c_double * GF_MAX_DIM),

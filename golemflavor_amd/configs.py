@@ -7,6 +7,7 @@ ranges, seeds, stds, priors, tags and declaration order -- the order is the colu
   C1/C2  notebook_paramsets()   examples/inference.ipynb cells 9 and 17 (6-dim, Gaussian llh)
   C3     unitary_paramset()     scripts/mc_unitary.py:28-41             (4-dim, flat priors)
   C4     texture_paramset(d)    scripts/mc_texture.py:28-76             (7-dim)
+  --     mcx_paramset()         scripts/mc_x.py:28-46                   (5-dim: 4 mixing + astroX)
   C5     fr_paramsets(d, inj)   scripts/fr.py:30-104                    (12-dim)
 """
 import numpy as np
@@ -109,6 +110,13 @@ def notebook_paramsets(asimov_angles, smearing=0.02):
 def unitary_paramset():
     """scripts/mc_unitary.py:28-41: four mixing parameters, all UNIFORM."""
     return ParamSet(_mixing_params(priors=False, eps_dcp=True))
+
+
+def mcx_paramset():
+    """scripts/mc_x.py:28-46: four mixing parameters (priors as scripts/fr.py) + the source parameter astroX,
+    source composition (x, 1 - x, 0)."""
+    return ParamSet(_mixing_params(True, True) + [
+        Param(name='astroX', value=0.5, seed=[0., 1.], ranges=[0., 1.], std=0.1, tex=r'x', tag=ParamTag.SRCANGLES)])
 
 
 def texture_paramset(dimension):

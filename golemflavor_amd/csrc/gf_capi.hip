@@ -304,6 +304,11 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
         if (!idx_ok(d->idx_mass[k]) || !idx_ok(d->idx_src[k])) return GF_ERR_INVALID_ARG;
     if (!idx_ok(d->idx_scale) || !idx_ok(d->idx_gamma)) return GF_ERR_INVALID_ARG;
     if ((d->idx_src[0] < 0) != (d->idx_src[1] < 0)) return GF_ERR_INVALID_ARG;
+    if (!idx_ok(d->idx_src_x) || (d->idx_src_x >= 0 && d->idx_src[0] >= 0)) return GF_ERR_INVALID_ARG;
+    if (d->idx_src_x >= 0 && d->mode == GF_MODE_BSM_GAUSS) {
+        std::snprintf(g_err, sizeof(g_err), "an astroX source column is not defined for the flux-averaged (BSM) posterior");
+        return GF_ERR_UNSUPPORTED;
+    }
     // CP phases (dcp, and the NP matrix's for texture NONE): the kernels' sine / cosine reduce |x| < GF_PHASE_MAX
     // only (every paramset of the reference boxes them into [0, 2 pi]: scripts/fr.py:41, mc_unitary.py:39)
     auto phase_ok = [&](int idx, double fixed) {
@@ -327,6 +332,7 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
     for (int k = 0; k < 2; ++k) { c.idx_mass[k] = d->idx_mass[k]; c.idx_src[k] = d->idx_src[k]; c.mass_fixed[k] = d->mass_fixed[k]; }
     c.idx_scale = d->idx_scale;
     c.idx_gamma = d->idx_gamma;
+    c.idx_src_x = d->idx_src_x;
     c.scale_fixed = d->scale_fixed;
 
     // priors: llh.py:81-90 + scipy truncnorm.logpdf = ((-z^2/2 - log sqrt(2pi)) - log_mass) - log(sigma)

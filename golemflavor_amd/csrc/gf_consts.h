@@ -17,7 +17,7 @@ struct GfCommon {
     int32_t idx_scale;
     int32_t idx_mm[4];
     int32_t idx_gamma;
-    int32_t pad_;
+    int32_t idx_src_x;              // astroX column: source = normalize_fr((x, 1 - x, 0)), scripts/mc_x.py:186-190; -1 = none
     double lo[GF_MAX_DIM];
     double hi[GF_MAX_DIM];
     double loc[GF_MAX_DIM];

@@ -373,6 +373,13 @@ __device__ __forceinline__ void sm_composition(const GfCommon& c, const double* 
     if (c.idx_src[0] >= 0) {
         angles_to_fr(row[c.idx_src[0]], row[c.idx_src[1]], src);
         src_sum = (src[0] + src[1]) + src[2];
+    } else if (c.idx_src_x >= 0) {
+        // scripts/mc_x.py:186-190: srcs = normalize_fr((x, 1 - x, 0)) = (x, 1 - x, 0) / float(sum), then u_to_fr
+        // divides by the sum of that again (fr.py:535)
+        const double x = row[c.idx_src_x], y = 1.0 - x;
+        const double inv = fast_rcp((x + y) + 0.0);
+        src[0] = x * inv; src[1] = y * inv; src[2] = 0.0;
+        src_sum = (src[0] + src[1]) + src[2];
     } else {
         src[0] = c.src_fixed[0]; src[1] = c.src_fixed[1]; src[2] = c.src_fixed[2];
         src_sum = c.src_fixed_sum;

@@ -44,7 +44,7 @@ def log_gauss_mass(a, b):
 
 def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=-320.0,
                   source_ratio=(1.0, 2.0, 0.0), texture=Texture.NONE, dimension=3, binning=None,
-                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=(0.0, 0.0, 0.0, 0.0),
+                  spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=None,
                   sm_fixed=None, src_columns=None):
     """Flatten a posterior definition into a `GfModelDesc`.
 
@@ -57,6 +57,11 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     sm_fixed     : the four mixing parameters used when they are not sampled (default: NuFIT, fr.py:313);
                    (0, 1, 0, 0) is the identity matrix, i.e. no oscillation (examples/tutorial.ipynb).
     src_columns  : the two columns holding the source flavor angles when they are not tagged SRCANGLES.
+    mm_fixed     : the four NP mixing parameters of Texture.NONE when they are not sampled (the tuple
+                   params_to_BSMu takes directly, fr.py:354-358,378).
+
+    A single SRCANGLES-tagged column is scripts/mc_x.py's `astroX` (mc_x.py:41-44): the source composition is
+    normalize_fr((x, 1 - x, 0)) of that column (mc_x.py:186-190).
     """
     params = list(llh_paramset)
     ndim = len(params)
@@ -101,7 +106,7 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     for k in range(4):
         d.idx_sm[k] = sm_idx[k]
         d.sm_fixed[k] = float(sm_fixed[k]) if sm_fixed is not None else NUFIT_ANGLES[k]
-        d.mm_fixed[k] = float(mm_fixed[k])
+        d.mm_fixed[k] = float(mm_fixed[k]) if mm_fixed is not None else 0.0
     for k in range(2):
         d.idx_mass[k] = mass_idx[k]
         d.mass_fixed[k] = MASS_EIGENVALUES[k]
@@ -109,12 +114,16 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     src_idx = [i for i, p in enumerate(params) if p.tag is ParamTag.SRCANGLES]
     if src_columns is not None:
         src_idx = [int(x) for x in src_columns]
+    d.idx_src_x = -1
     if len(src_idx) == 2:
         d.idx_src[0], d.idx_src[1] = src_idx
     elif not src_idx:
         d.idx_src[0] = d.idx_src[1] = -1
+    elif len(src_idx) == 1:
+        d.idx_src[0] = d.idx_src[1] = -1
+        d.idx_src_x = src_idx[0]
     else:
-        raise ValueError("expected 0 or 2 SRCANGLES params, got %d" % len(src_idx))
+        raise ValueError("expected 0, 1 (astroX) or 2 SRCANGLES params, got %d" % len(src_idx))
     for k in range(3):
         d.source_ratio[k] = float(source_ratio[k])
 
@@ -139,8 +148,8 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     if d.mode == _lib.GF_MODE_BSM_GAUSS:
         if binning is None:
             raise ValueError("BSM mode needs the energy bin edges")
-        if d.texture == Texture.NONE.value and len(mm_idx) != 4:
-            raise ValueError("texture NONE needs four MMANGLES params (fr.py:378)")
+        if d.texture == Texture.NONE.value and len(mm_idx) != 4 and mm_fixed is None:
+            raise ValueError("texture NONE needs four MMANGLES params (fr.py:378) or an explicit mm_fixed")
         if d.idx_scale < 0 and scale_fixed is None:
             raise ValueError("BSM mode needs a SCALE-tagged param (logLam) or an explicit scale_fixed")
         edges = np.asarray(binning, dtype=np.float64)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 1
+#define GF_ABI_VERSION 2
 #define GF_MAX_DIM 16
 #define GF_MAX_BINS 64
 /* CP phases (dcp; the NP matrix's for texture NONE) must stay within +-GF_PHASE_MAX: range (sampled) or value
@@ -91,6 +91,9 @@ typedef struct gf_model_desc {
     int32_t idx_scale;                 /* logLam (fr.py:380)                                    */
     int32_t idx_mm[4];                 /* NP mixing angles when texture == NONE (fr.py:378)     */
     int32_t idx_gamma;                 /* astroDeltaGamma (llh.py:105); cancels in fr, kept for fidelity */
+    int32_t idx_src_x;                 /* astroX: the source is normalize_fr((x, 1 - x, 0)) with x = this column
+                                          (scripts/mc_x.py:43,186-190); -1 = not used; excludes idx_src      */
+    int32_t reserved0;                 /* 0                                                     */
     int32_t prior_kind[GF_MAX_DIM];    /* gf_prior_kind per column (llh.py:81-90)               */
     double lo[GF_MAX_DIM];             /* Param.ranges[0]  (closed box, llh.py:74-78)           */
     double hi[GF_MAX_DIM];             /* Param.ranges[1]                                       */

@@ -36,7 +36,7 @@ class OrcModel(C.Structure):
         ("ndim", C.c_int32), ("mode", C.c_int32), ("texture", C.c_int32),
         ("dimension", C.c_int32), ("nbins", C.c_int32),
         ("idx_sm", C.c_int32 * 4), ("idx_mass", C.c_int32 * 2), ("idx_src", C.c_int32 * 2),
-        ("idx_scale", C.c_int32), ("idx_mm", C.c_int32 * 4), ("idx_gamma", C.c_int32),
+        ("idx_scale", C.c_int32), ("idx_mm", C.c_int32 * 4), ("idx_gamma", C.c_int32), ("idx_src_x", C.c_int32),
         ("kind", C.c_int32 * MAX_DIM),
         ("lo", C.c_double * MAX_DIM), ("hi", C.c_double * MAX_DIM),
         ("loc", C.c_double * MAX_DIM), ("sigma", C.c_double * MAX_DIM),
@@ -89,6 +89,7 @@ def lib():
         L.orc_log_gauss_mass.argtypes = [C.c_double, C.c_double]
         L.orc_log_gauss_mass.restype = C.c_double
         L.orc_unitarity_residual_batch.argtypes = [mp, dp, C.c_int64, dp]
+        L.orc_unitarity_residual_batch_sc2.argtypes = [mp, dp, C.c_int64, dp, dp]
         up = C.POINTER(C.c_uint32)
         L.orc_philox_raw.argtypes = [up, up, up]
         L.orc_haar_draw.argtypes = [dp, C.c_uint64, C.c_int64, C.c_int64, dp, dp]
@@ -166,7 +167,7 @@ def _name(e):
 
 def make_model(paramset, mode, *, bestfit_fr=(1 / 3, 1 / 3, 1 / 3), smearing=0.02, offset=-320.0,
                source_ratio=(1.0, 2.0, 0.0), texture="NONE", dimension=3, binning=None,
-               spectral_index=-2.0, flat_llh=1.0, scale_fixed=0.0, sm_fixed=None, src_columns=None):
+               spectral_index=-2.0, flat_llh=1.0, scale_fixed=0.0, sm_fixed=None, src_columns=None, mm_fixed=None):
     """Flatten (paramset, args) into the oracle's POD model.
 
     `source_ratio` is used as given (the scripts normalise it first, scripts/fr.py:118).
@@ -220,10 +221,13 @@ def make_model(paramset, mode, *, bestfit_fr=(1 / 3, 1 / 3, 1 / 3), smearing=0.0
     src_idx = [i for i, t in enumerate(tags) if t == "SRCANGLES"]
     if src_columns is not None:
         src_idx = [int(x) for x in src_columns]
+    m.idx_src_x = -1
     if len(src_idx) == 2:
         m.idx_src[0], m.idx_src[1] = src_idx
     else:
         m.idx_src[0] = m.idx_src[1] = -1
+        if len(src_idx) == 1:          # scripts/mc_x.py:41-44 astroX
+            m.idx_src_x = src_idx[0]
     for k in range(3):
         m.source_ratio[k] = float(source_ratio[k])
 
@@ -233,7 +237,7 @@ def make_model(paramset, mode, *, bestfit_fr=(1 / 3, 1 / 3, 1 / 3), smearing=0.0
     mm_idx = [i for i, t in enumerate(tags) if t == "MMANGLES"]
     for k in range(4):
         m.idx_mm[k] = mm_idx[k] if len(mm_idx) == 4 else -1
-        m.mm_fixed[k] = 0.0
+        m.mm_fixed[k] = float(mm_fixed[k]) if mm_fixed is not None else 0.0
     m.idx_gamma = idx("astroDeltaGamma")
     m.gamma_fixed = float(spectral_index)
 
@@ -308,9 +312,15 @@ def haar_draw(source_ratio, seed, n, first=0):
     return fr, ang
 
 
-def unitarity_residual_batch(model, theta):
-    """Worst max(|tr|XX^+|-3|, |sum|XX^+|-3|) over the energy bins, per walker (fr.py:489-494)."""
+def unitarity_residual_batch(model, theta, sc2=None):
+    """Worst max(|tr|XX^+|-3|, |sum|XX^+|-3|) over the energy bins, per walker (fr.py:489-494).  `sc2`: per-walker
+    values to use for 10**logLam instead of libm's pow (the ones the reference's numpy produced, golden G17)."""
     th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(-1, model.ndim))
     out = np.empty(th.shape[0])
-    lib().orc_unitarity_residual_batch(C.byref(model), _dp(th), th.shape[0], _dp(out))
+    if sc2 is None:
+        lib().orc_unitarity_residual_batch(C.byref(model), _dp(th), th.shape[0], _dp(out))
+    else:
+        s = np.ascontiguousarray(np.asarray(sc2, dtype=np.float64).reshape(-1))
+        assert s.size == th.shape[0]
+        lib().orc_unitarity_residual_batch_sc2(C.byref(model), _dp(th), th.shape[0], _dp(s), _dp(out))
     return out

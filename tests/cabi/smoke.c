@@ -37,7 +37,7 @@ int main(int argc, char** argv)
     for (int k = 0; k < 4; ++k) { d.idx_sm[k] = k; d.idx_mm[k] = -1; }
     d.idx_src[0] = 4; d.idx_src[1] = 5;
     d.idx_mass[0] = d.idx_mass[1] = -1;
-    d.idx_scale = d.idx_gamma = -1;
+    d.idx_scale = d.idx_gamma = d.idx_src_x = -1;
     for (int k = 0; k < 3; ++k) d.bestfit_fr[k] = atof(argv[1 + k]);
     d.smearing = 0.02;
     d.offset = -320.0;

@@ -22,7 +22,18 @@ def golden():
     # G10 (examples/tutorial.ipynb posterior) lives in its own file, tests/golden/make_golden_tutorial.py
     with np.load(os.path.join(ROOT, "tests", "golden", "golden_tutorial.npz"), allow_pickle=False) as z:
         out.update({k: z[k] for k in z.files})
+    # G11-G17 (second round): tests/golden/make_golden_r2.py
+    with np.load(os.path.join(ROOT, "tests", "golden", "golden_r2.npz"), allow_pickle=False) as z:
+        out.update({k: z[k] for k in z.files})
     return out
+
+
+@pytest.fixture(scope="session")
+def golden_meta():
+    """Non-array fixtures of make_golden_r2.py (G16: identifier strings of misc.gen_identifier)."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "golden_r2_meta.json")) as f:
+        return json.load(f)
 
 
 @pytest.fixture(scope="session")
