@@ -120,7 +120,7 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_descriptor_struct_layout_matches_header():
     # the C side static-asserts nothing about Python; cross-check the size from the header's field list
-    n_i32 = 6 + 4 + 2 + 2 + 1 + 4 + 1 + 16
+    n_i32 = 6 + 4 + 2 + 2 + 1 + 4 + 1 + 2 + 16
     n_f64 = 16 * 5 + 4 + 2 + 3 + 1 + 4 + 1 + 3 + 1 + 1 + 1 + 65
     assert C.sizeof(_lib.GfModelDesc) == 4 * n_i32 + 8 * n_f64
     assert _lib.lib().gf_sizeof_model_desc() == C.sizeof(_lib.GfModelDesc)
