@@ -20,9 +20,11 @@
 //
 // Error behaviour.  The reference raises AssertionError when its computed eigenvector matrix X fails
 // |tr|XX^+| - 3| < 1e-7 and |sum|XX^+| - 3| < 1e-7 (fr.py:461-499).  In exact arithmetic X is exactly
-// unitary: the failure *is* the rounding noise of the (conj(B)C, AC, AB) form.  When a status array is
-// requested the kernel evaluates that same form in fp64 and reports GF_ST_NON_UNITARY when its residual
-// exceeds 1e-7 * 2^11 (fp64 / x87 unit-roundoff ratio) -- the same noise, 2^11 times louder.
+// unitary: the failure *is* the rounding noise of the (conj(B)C, AC, AB) form in the x87 format.  When a status
+// array is requested the kernel evaluates that same form in fp64 -- the same noise, 2^11 times louder -- as an
+// estimate: far below the threshold the walker is unitary, far above it GF_ST_NON_UNITARY, and the (walker, bin)
+// pairs in between are queued for gf_unitarity.hip, which replays the reference's operations in emulated x87
+// arithmetic and decides (gf_x87.hpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                      int32_t* __restrict__ status)
+                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, int64_t qbase)
 {
     // the constants by pointer (the model's device block), not by value: as a 848-B kernel argument the compiler loads
     // every field up front and spills ~100 scalar registers to VGPR lanes around the tile loop (356 v_readlane /
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
     const int wave = threadIdx.x / GF_WAVE;
     const int ndim = NDIM ? NDIM : c.ndim;
     const int sub = LPW > 1 ? lane % LPW : 0;
-    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * (3 * tb->nbins + LPW) : nullptr;
+    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * GF_FGRP_DOUBLES(tb->nbins, LPW) : nullptr;
     double* tile = tiles[wave];
     const int64_t ntiles = (n + WPT - 1) / WPT;
     const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
@@ -91,9 +93,21 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
                 double residual = 0.0;
-                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, residual, sub, fgrp);
+                unsigned long long amb = 0;
+                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, residual, amb, sub, fgrp);
                 st = ST_OK;
-                if (CHECK_UNI && !(residual < UNI_THRESHOLD)) st = ST_NON_UNITARY;
+                if (CHECK_UNI) {
+                    if (!(residual < UNI_HI)) st = ST_NON_UNITARY;
+                    else if (amb != 0 && sub == 0 && uq) {
+                        // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
+                        // walker counts as unitary.  Walker indices in the queue are those of the whole batch.
+                        const unsigned int cnt = (unsigned int)__popcll(amb);
+                        const unsigned int at = atomicAdd(&uq->count, cnt);
+                        unsigned int j = 0;
+                        for (unsigned long long mrest = amb; mrest != 0; mrest &= mrest - 1, ++j)
+                            if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)(qbase + i) * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
+                    }
+                }
                 if (WITH_LLH) {
                     // llh.py:109-112: fr -> fr_to_angles -> (Gaussian substitute) angles_to_fr is the
                     // identity on a normalised composition up to rounding
@@ -136,7 +150,7 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
     if (nbins < 2) return 1;
     const int64_t simds = 4 * (int64_t)(cus > 0 ? cus : 256);
     const int64_t waves1 = (n + GF_WAVE - 1) / GF_WAVE;
-    auto fits = [&](int lpw) { return (size_t)(GF_BLOCK / lpw) * (3 * nbins + lpw) * sizeof(double) <= 32 * 1024; };
+    auto fits = [&](int lpw) { return (size_t)(GF_BLOCK / lpw) * GF_FGRP_DOUBLES(nbins, lpw) * sizeof(double) <= 32 * 1024; };
     if (waves1 * 16 <= simds && fits(16)) return 16;
     if (waves1 * 4 <= 2 * simds && fits(4)) return 4;
     return 1;
@@ -144,12 +158,12 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 
 template <int NDIM, int LPW>
 hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase, int cus, hipStream_t s)
 {
     const int grid = grid_for(n * LPW, GF_BLOCK, cus);
-    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * (3 * nbins + LPW) * sizeof(double) : 0;
+    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * GF_FGRP_DOUBLES(nbins, LPW) * sizeof(double) : 0;
     const bool chk = status != nullptr;
-#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status)
+#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status, uq, qbase)
     if (with_llh) { if (chk) GF_GO(true, true); else GF_GO(true, false); }
     else          { if (chk) GF_GO(false, true); else GF_GO(false, false); }
 #undef GF_GO
@@ -158,23 +172,49 @@ hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d
 
 template <int NDIM>
 hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
-                    int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase, int cus, hipStream_t s)
 {
     switch (lanes_for(n, nbins, cus, status != nullptr)) {
-    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
     }
 }
 
 }  // namespace
 
-hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, int cus, hipStream_t s)
+// One launch of the evaluation kernel over walkers [0, n) of the block at `theta` (AoS: rows; SoA: the caller passes the
+// whole batch and `n` = its size).  `uq` (status requested): where undecided (walker, bin) pairs go; `qbase` is added to
+// the walker index in the queue.
+static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta,
+                              int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase,
+                              int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
-    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, cus, s);
+    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
     }
+}
+
+// `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested.  With a status array
+// an AoS batch is cut into pieces whose worst case (every bin of every walker undecided) fits the queue, each piece
+// followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
+hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, int cus, hipStream_t s)
+{
+    if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, 0, cus, s);
+    int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
+    if (piece < 1) piece = 1;
+    if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n
+    for (int64_t w0 = 0; w0 < n; w0 += piece) {
+        const int64_t m = n - w0 < piece ? n - w0 : piece;
+        hipError_t e = launch_eval(c, d_common, d_bsm, nbins, ptab, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, with_llh,
+                                   lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, 0, cus, s);
+        if (e != hipSuccess) return e;
+        e = gf_launch_uni_resolve(d_common, d_bsm, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, c.ndim,
+                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, m * nbins, cus, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }

@@ -6,7 +6,16 @@
 namespace gfdev {
 
 constexpr int TEX_NONE = 4;
-constexpr double UNI_THRESHOLD = 1e-7 * 2048.0;
+// The unitarity residual of the reference (fr.py:489-494, threshold 1e-7) is x87 rounding noise; the kernels evaluate the
+// same eigenvector form in fp64, whose residual `rr` is that noise 2^11 times louder -- an ESTIMATE, good to about two
+// decades either way.  rr / 2^11 below UNI_LO: unitary for the reference too; above UNI_HI: not unitary; in between the
+// (walker, bin) pair is queued for the x87-faithful evaluation of gf_unitarity.hip, which decides.
+constexpr double UNI_EST_SCALE = 2048.0;
+constexpr double UNI_THRESHOLD = 1e-7 * UNI_EST_SCALE;    // estimate-only verdict
+constexpr double UNI_LO = 1e-9 * UNI_EST_SCALE;
+constexpr double UNI_HI = 1e-5 * UNI_EST_SCALE;
+// doubles of LDS a group of LPW lanes sharing one walker needs: [nb][3] compositions, LPW residuals, LPW bin masks
+#define GF_FGRP_DOUBLES(nb, lpw) (3 * (nb) + 2 * (lpw))
 
 struct Herm3 {          // 3x3 Hermitian: real diagonal + the three upper off-diagonals
     double d0, d1, d2;
@@ -135,7 +144,7 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 // Optionally the reference's eigenvector form for the unitarity status.
 template <bool CHECK_UNI>
 __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
-                                           double p[3][3], double& residual)
+                                           double p[3][3], double& residual, unsigned long long& amb, int kbin)
 {
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
@@ -217,6 +226,7 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
         double rr = 2.0 * off;                                         // |sum|XX^+| - 3| with the trace at 3
         if (rr != rr) rr = gf_inf();                                   // NaN fails the reference's test too
         residual = fmax(residual, rr);
+        if (rr >= UNI_LO) amb |= 1ull << kbin;                         // this bin's verdict is not safe from the estimate
     }
 }
 
@@ -225,13 +235,13 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
 //
 // LPW > 1 (device sampler on small ensembles): LPW adjacent lanes of one wave hold the SAME walker; each
 // computes the walker's invariants (redundantly, bit-identical) and the bins k = sub, sub + LPW, ...; the
-// per-bin compositions meet in LDS (`fgrp`: [nb][3] doubles + LPW residuals, private to the lane group) and
+// per-bin compositions meet in LDS (`fgrp`: GF_FGRP_DOUBLES(nb, LPW) doubles, private to the lane group) and
 // every lane then runs the same in-order weighted sum, so the result is bitwise the LPW = 1 result on all LPW
 // lanes.  The walker's critical path drops from nb bins to ceil(nb / LPW).
 template <bool CHECK_UNI, int LPW = 1>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
-                                             const double* row, double fr[3], double& residual, int sub = 0,
-                                             double* fgrp = nullptr)
+                                             const double* row, double fr[3], double& residual, unsigned long long& amb,
+                                             int sub = 0, double* fgrp = nullptr)
 {
     // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
     double c1r[3], c1i[3], c2r[3], c2i[3];
@@ -268,7 +278,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
-        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual);
+        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual, amb, k);
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
         const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
         const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
@@ -284,7 +294,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         }
     }
     if (LPW > 1) {
-        if (CHECK_UNI) fgrp[3 * nb + sub] = residual;
+        if (CHECK_UNI) { fgrp[3 * nb + sub] = residual; fgrp[3 * nb + LPW + sub] = __longlong_as_double((long long)amb); }
         // the lanes of a group sit in one wave: its LDS operations retire in order, the fence keeps the compiler honest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -295,7 +305,10 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         }
         if (CHECK_UNI) {
 #pragma unroll
-            for (int j = 0; j < LPW; ++j) residual = fmax(residual, fgrp[3 * nb + j]);
+            for (int j = 0; j < LPW; ++j) {
+                residual = fmax(residual, fgrp[3 * nb + j]);
+                amb |= (unsigned long long)__double_as_longlong(fgrp[3 * nb + LPW + j]);
+            }
         }
     }
     const double inv = fast_rcp((a0 + a1) + a2);                    // fr.py:457

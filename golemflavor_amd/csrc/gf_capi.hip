@@ -7,6 +7,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -52,6 +53,46 @@ void mixing_matrix_ld(const double ang[4], cld u[3][3])
     u[2][0] = s12 * s23 - c12 * c23 * s13 * ep;  u[2][1] = -c12 * s23 - s12 * c23 * s13 * ep; u[2][2] = c23 * c13;
 }
 
+// golemflavor/fr.py:138-161 angles_to_u operation by operation in long double (np.float128 on x86-64, the same libm):
+// U = np.dot(np.dot(p1, p2), p3), np.dot accumulating from zero in index order.  Host side, once per model, for the
+// per-model matrices of the unitarity arbitration (gf_unitarity.hip) -- their entries must be the reference's to the
+// last bit, not merely to 1e-19.
+void angles_to_u_ref_ld(const double ang[4], cld u[3][3])
+{
+    const ld s12_2 = ang[0], c13_4 = ang[1], s23_2 = ang[2];
+    const ld c13_2 = sqrtl(c13_4);
+    const ld t12 = asinl(sqrtl(s12_2)), t13 = acosl(sqrtl(c13_2)), t23 = asinl(sqrtl(s23_2));
+    const ld c12 = cosl(t12), s12 = sinl(t12), c13 = cosl(t13), s13 = sinl(t13), c23 = cosl(t23), s23 = sinl(t23);
+    const ld dcp = ang[3];
+    const cld em(cosl(dcp), -sinl(dcp)), ep(cosl(dcp), sinl(dcp));      // EXP(-+1j * dcp)
+    auto mul = [](cld a, cld b) { return cld(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real()); };
+    auto dot = [&](const cld a[3][3], const cld b[3][3], cld out[3][3]) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                cld acc(0.0L, 0.0L);
+                for (int k = 0; k < 3; ++k) { const cld p = mul(a[i][k], b[k][j]); acc = cld(acc.real() + p.real(), acc.imag() + p.imag()); }
+                out[i][j] = acc;
+            }
+    };
+    const cld p1[3][3] = {{1.0L, 0.0L, 0.0L}, {0.0L, c23, s23}, {0.0L, -s23, c23}};
+    const cld p2[3][3] = {{c13, 0.0L, cld(s13 * em.real(), s13 * em.imag())}, {0.0L, 1.0L, 0.0L}, {cld(-s13 * ep.real(), -s13 * ep.imag()), 0.0L, c13}};
+    const cld p3[3][3] = {{c12, s12, 0.0L}, {-s12, c12, 0.0L}, {0.0L, 0.0L, 1.0L}};
+    cld t[3][3];
+    dot(p1, p2, t);
+    dot(t, p3, u);
+}
+
+void split_matrix_ld(const cld u[3][3], double hi[18], double lo[18])
+{
+    for (int k = 0; k < 9; ++k) {
+        const ld v[2] = {u[k / 3][k % 3].real(), u[k / 3][k % 3].imag()};
+        for (int q = 0; q < 2; ++q) {
+            hi[2 * k + q] = (double)v[q];
+            lo[2 * k + q] = (double)(v[q] - (ld)hi[2 * k + q]);
+        }
+    }
+}
+
 bool finite_all(const double* p, int n)
 {
     for (int i = 0; i < n; ++i)
@@ -81,6 +122,11 @@ struct gf_model {
     size_t h_pin_bytes = 0;
     double* d_cube = nullptr;    // gf_lnprob_cube_batch: the unit-cube rows on the device
     size_t cube_cap = 0;
+    // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
+    GfUniQueue* d_uq = nullptr;
+    int64_t uq_cap = 0;
+    GfUniQueue h_uq_hdr = {0, 0, 0, 0, {0}};
+    std::mutex call_mu;          // serialises the entry points that use the model's staging buffers / queue
 };
 
 namespace {
@@ -198,13 +244,43 @@ int check_dev_ptr(const void* p, size_t align)
     return GF_OK;
 }
 
+// The arbitration queue must hold every (walker, bin) pair of one piece of the batch (gf_launch_bsm cuts AoS batches
+// into pieces of uq_cap / nbins walkers; SoA batches go in one piece).
+constexpr int64_t UQ_MAX_ITEMS = 1 << 24;      // 128 MB of items: ~840 k walkers x 20 bins per piece
+
+int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
+{
+    const int64_t nb = m->hb.nbins > 0 ? m->hb.nbins : 1;
+    int64_t need = n * nb;
+    if (layout == GF_LAYOUT_AOS && need > UQ_MAX_ITEMS) need = UQ_MAX_ITEMS > nb ? UQ_MAX_ITEMS : nb;
+    if (need <= m->uq_cap) return GF_OK;
+    if (need > 0xffffffffLL) {
+        std::snprintf(g_err, sizeof(g_err), "a structure-of-arrays batch of %lld walkers with a status array exceeds the arbitration queue", (long long)n);
+        return GF_ERR_UNSUPPORTED;
+    }
+    int64_t cap = m->uq_cap ? m->uq_cap : 4096;
+    while (cap < need) cap *= 2;
+    GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
+    if (m->d_uq) (void)hipFree(m->d_uq);
+    m->d_uq = nullptr; m->uq_cap = 0;
+    GF_HIP(hipMalloc((void**)&m->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
+    m->h_uq_hdr.count = 0; m->h_uq_hdr.done = 0; m->h_uq_hdr.cap = (unsigned int)cap; m->h_uq_hdr.pad_ = 0;
+    GF_HIP(hipMemcpyAsync(m->d_uq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
+    GF_HIP(hipStreamSynchronize(st));
+    m->uq_cap = cap;
+    return GF_OK;
+}
+
 int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,
                   int32_t* d_status)
 {
     if (n == 0) return GF_OK;
     hipError_t e;
-    if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, m->cus, st);
+    if (m->c.mode == GF_MODE_BSM_GAUSS) {
+        if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status,
+                          d_status ? m->d_uq : nullptr, m->uq_cap, m->cus, st);
+    }
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
@@ -215,8 +291,11 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
 {
     if (n == 0) return GF_OK;
     hipError_t e;
-    if (m->c.mode == GF_MODE_BSM_GAUSS)
-        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status, m->cus, st);
+    if (m->c.mode == GF_MODE_BSM_GAUSS) {
+        if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status,
+                          d_status ? m->d_uq : nullptr, m->uq_cap, m->cus, st);
+    }
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");
@@ -417,6 +496,22 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
                     b.t2_re[3 * i + j] = (double)t2.real(); b.t2_im[3 * i + j] = (double)t2.imag();
                 }
         }
+        // per-model matrices of the unitarity arbitration, in the reference's own operation order
+        {
+            const double z = 0. + 1e-9;                                            // fr.py:370
+            double np_ang[4];
+            switch (d->texture) {
+            case GF_TEX_OEU: np_ang[0] = 0.5; np_ang[1] = 1.0; np_ang[2] = z; np_ang[3] = z; break;
+            case GF_TEX_OET: np_ang[0] = z; np_ang[1] = 0.25; np_ang[2] = z; np_ang[3] = z; break;
+            case GF_TEX_OUT: np_ang[0] = z; np_ang[1] = 1.0; np_ang[2] = 0.5; np_ang[3] = z; break;
+            default: for (int k = 0; k < 4; ++k) np_ang[k] = d->mm_fixed[k]; break;   // used only when idx_mm < 0
+            }
+            cld u[3][3];
+            angles_to_u_ref_ld(np_ang, u);
+            split_matrix_ld(u, b.npu_hi, b.npu_lo);
+            angles_to_u_ref_ld(d->sm_fixed, u);                                     // fr.py:313, 435
+            split_matrix_ld(u, b.smu_hi, b.smu_lo);
+        }
     }
 
     int cus = 256;
@@ -468,6 +563,7 @@ void gf_model_destroy(gf_model* m)
     if (m->d_status) (void)hipFree(m->d_status);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
     if (m->d_cube) (void)hipFree(m->d_cube);
+    if (m->d_uq) (void)hipFree(m->d_uq);
     delete m;
 }
 
@@ -498,6 +594,7 @@ int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int lay
                        double* d_fr, int32_t* d_status)
 {
     if (!m || n < 0) return GF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->call_mu);
     return launch_lnprob(m, (hipStream_t)stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
 }
 
@@ -505,6 +602,7 @@ int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int 
                           int32_t* d_status)
 {
     if (!m || n < 0) return GF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->call_mu);
     return launch_propagate(m, (hipStream_t)stream, d_theta, layout, n, d_fr, d_status);
 }
 
@@ -514,6 +612,8 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
 {
     if (!m || n < 0 || (n > 0 && (!theta || (with_llh && !lnprob) || (!with_llh && !fr)))) return GF_ERR_INVALID_ARG;
     if (n == 0) return GF_OK;
+    // one caller at a time per model: the staging buffers (and the arbitration queue) are the model's
+    std::lock_guard<std::mutex> lk(m->call_mu);
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
     int rc = ensure_staging(m, n);
@@ -576,6 +676,7 @@ int gf_lnprob_cube_batch(gf_model* m, const double* cube, int64_t n, int nscan, 
         seen[cols[k]] = true;
     }
     if (n == 0) return GF_OK;
+    std::lock_guard<std::mutex> lk(m->call_mu);
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
     int rc = ensure_staging(m, n);
@@ -689,6 +790,7 @@ int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
+    std::lock_guard<std::mutex> lk(m->call_mu);
     return launch_lnprob(m, m->stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
 }
 
@@ -702,6 +804,7 @@ int gf_propagate_batch_device(gf_model* m, const double* d_theta, int layout, in
     if (rc != GF_OK) return rc;
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
+    std::lock_guard<std::mutex> lk(m->call_mu);
     return launch_propagate(m, m->stream, d_theta, layout, n, d_fr, d_status);
 }
 

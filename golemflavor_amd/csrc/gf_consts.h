@@ -56,4 +56,20 @@ struct GfBsm {
     double epow[GF_MAX_BINS];       // E_k ** (d - 3)             fr.py:394
     double weight[GF_MAX_BINS];     // |b_{k+1} - b_k|            fr.py:414 (the 1/(b_N - b_0) factor cancels in fr.py:457)
     double centre[GF_MAX_BINS];     // sqrt(b_k b_{k+1})          fr.py:413
+    // Unitarity arbitration (gf_unitarity.hip, gf_x87.hpp): per-model mixing matrices in the reference's own
+    // arithmetic -- angles_to_u (fr.py:116-162) evaluated in long double by gf_model_create, each entry split into
+    // (hi, lo) doubles; row-major (re, im) pairs.  npu: the NP matrix of a fixed texture or of fixed NP angles;
+    // smu: the SM matrix when its angles are not columns of theta (NuFIT default, fr.py:313,435).
+    double npu_hi[18], npu_lo[18];
+    double smu_hi[18], smu_lo[18];
+};
+
+// Work queue of the unitarity arbitration: (walker, energy bin) pairs whose fp64 estimate of the reference's
+// unitarity residual cannot decide the verdict.  item = walker * 64 + bin.
+struct GfUniQueue {
+    unsigned int count;             // items pushed by the evaluation kernel of the current launch
+    unsigned int done;              // blocks of the resolve kernel that have finished (the last one resets both)
+    unsigned int cap;               // capacity of items[]
+    unsigned int pad_;
+    unsigned long long items[1];    // [cap]
 };

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
 }
 
 #if defined(GF_ASM_PIPE) || defined(GF_EXPERIMENTAL_RING)
-#include "gf_sm_experiments.hpp"   // measured alternatives, not built by default
+#include "../../tools/experiments/gf_sm_experiments.hpp"   // measured alternatives, not built by default
 #endif
 
 

@@ -99,7 +99,8 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
         st = ST_OUT_OF_PRIOR;
         if (inbox) {
             double residual = 0.0;
-            flux_average<true, LPW>(c, tb, ttab, row, fr, residual, sub, fgrp);
+            unsigned long long amb = 0;
+            flux_average<true, LPW>(c, tb, ttab, row, fr, residual, amb, sub, fgrp);
             st = (residual < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
                                              const StretchArgs& s, const int chain, const int k, const bool valid, const int sub)
 {
     extern __shared__ __attribute__((aligned(16))) double fdyn[];    // LPW > 1: per lane group [nbins_max][3] + [LPW]
-    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * (3 * s.nbins_max + LPW) : nullptr;
+    double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * GF_FGRP_DOUBLES(s.nbins_max, LPW) : nullptr;
     constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
     __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * ND];
     __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
@@ -238,7 +239,7 @@ inline int lanes_per_walker(int mode, int64_t walkers, int nbins_max, int cus)
     if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
     const int64_t want = (int64_t)cus * 4 * 4;
     for (int lpw : {1, 4, 16}) {
-        const size_t lds = (size_t)(GF_BLOCK / lpw) * (3 * nbins_max + lpw) * sizeof(double);
+        const size_t lds = (size_t)(GF_BLOCK / lpw) * GF_FGRP_DOUBLES(nbins_max, lpw) * sizeof(double);
         if (lpw > 1 && lds > 40 * 1024) return lpw == 4 ? 1 : 4;      // group buffers no longer fit beside the tiles
         if ((walkers * lpw + GF_WAVE - 1) / GF_WAVE >= want || lpw == 16) return lpw;
     }
@@ -248,7 +249,7 @@ inline int lanes_per_walker(int mode, int64_t walkers, int nbins_max, int cus)
 template <int NDIM, int MODE, int LPW>
 hipError_t launch_stretch_nml(const GfCommon& c, const GfBsm* tb, const double* ptab, const StretchArgs& a, hipStream_t st)
 {
-    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * (3 * a.nbins_max + LPW) * sizeof(double) : 0;
+    const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * GF_FGRP_DOUBLES(a.nbins_max, LPW) * sizeof(double) : 0;
     if (a.commons) {
         const dim3 grid((unsigned)(((int64_t)(a.nwalkers / 2) * LPW + GF_BLOCK - 1) / GF_BLOCK), a.nchains);
         hipLaunchKernelGGL((k_stretch_multi<NDIM, MODE, LPW>), grid, dim3(GF_BLOCK), lds, st, a);

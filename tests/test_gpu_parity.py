@@ -215,6 +215,13 @@ def _status_must_agree(oracle, om, theta):
     return (r80 < 1e-9) | (r80 > 1e-5)
 
 
+def _status_must_agree_with_oracle(r80):
+    """Against the ORACLE (same libm 10**x as the device's correctly rounded one): the device replays the reference's
+    operations in emulated x87 arithmetic and only a last-bit difference in a transcendental function can move the
+    residual (by less than a factor two, tests/test_x87_emulation.py): equality outside half a decade around 1e-7."""
+    return (r80 < 10 ** -7.25) | (r80 > 10 ** -6.75)
+
+
 def _bsm_models(oracle, ps, dim, tex, src, bf, with_llh):
     mode = "BSM_GAUSS"
     om = oracle.make_model(ps, mode, texture=tex.name, dimension=dim, binning=BIN_EDGES, source_ratio=src,
@@ -307,33 +314,49 @@ def test_bsm_random_vs_oracle(oracle, dim, tex):
     fin = clean & np.isfinite(ref)
     assert rel_err(lp[fin], ref[fin]) <= REL
     assert np.abs(fr[st != 1].sum(axis=1) - 1).max() < 1e-13
-    # status agreement: the emulated unitarity verdict matches the oracle's on nearly every walker
-    agree = np.mean((st == _lib.GF_ST_NON_UNITARY) == (ref_st == 2))
-    assert agree >= 0.98
+    # the unitarity verdict is the oracle's on every walker outside half a decade around the threshold
+    dec = _status_must_agree_with_oracle(r80)
+    assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[dec], (ref_st == 2)[dec])
+    assert np.mean((st == _lib.GF_ST_NON_UNITARY) == (ref_st == 2)) >= 0.999
     # without a status array the kernel skips the unitarity emulation; values are identical
     same = (st == 0)
     assert np.array_equal(lp[same], lp_nochk[same], equal_nan=True)
 
 
 def test_bsm_texture_none_sampled_np_angles(oracle):
-    """Texture.NONE: the four NP mixing angles are sampled (MMANGLES, fr.py:378)."""
+    """Texture.NONE: the four NP mixing angles are sampled (MMANGLES, fr.py:378).  Random walkers vs the oracle with the
+    bars of every other BSM test (reference-generated rows: test_gpu_parity_r2.py::test_bsm_texture_none_golden):
+    1e-10 where the oracle's own eigenvector matrix is unitary to 1e-13, 1e-10 + 10 r80 elsewhere, and <= 1e-11 from the
+    exact (60-digit) value on a sample of rows drawn from where the two differ most."""
+    from exact_mp import mp_flux_avg
     base = list(Cf.texture_paramset(3))
     mm = [Param(name="np_%s" % n, value=0.5, ranges=r, tag=ParamTag.MMANGLES)
           for n, r in (("s12", [0., 1.]), ("c13", [0., 1.]), ("s23", [0., 1.]), ("dcp", [0., 2 * np.pi]))]
     ps = ParamSet(base[:6] + mm + base[6:])
     rng = np.random.default_rng(77)
     th = uniform_theta(ps, 4000, rng, seeds=True)
-    th[:, 10] = rng.uniform(-32, -24, len(th))
+    th[:, 10] = rng.uniform(-32, -20, len(th))
     src = np.array([0., 1., 0.])
     om, desc = _bsm_models(oracle, ps, 3, Texture.NONE, src, (0.3, 0.4, 0.3), True)
     ref, ref_fr, ref_st = oracle.lnprob_batch(om, th, want_fr=True, want_status=True)
+    r80 = oracle.unitarity_residual_batch(om, th)
     with Model(desc) as m:
         lp, fr, st = m.lnprob(th, want_fr=True)
+    clear = _status_must_agree_with_oracle(r80)
+    assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[clear], (ref_st == 2)[clear])
     good = (ref_st == 0) & (st == 0)
-    assert good.mean() > 0.9
-    assert np.abs(fr[good] - ref_fr[good]).max() <= 1e-9
-    fin = good & np.isfinite(ref)
-    assert rel_err(lp[fin], ref[fin]) <= 1e-8
+    err = np.abs(fr - ref_fr).max(axis=1)
+    assert np.all(err[good] <= ABS_FR + 10.0 * r80[good])
+    clean = good & (r80 < 1e-13)
+    assert clean.sum() > 1500 and err[clean].max() <= ABS_FR
+    fin = clean & np.isfinite(ref)
+    assert rel_err(lp[fin], ref[fin]) <= REL
+    # exact arbitration: the 40 evaluated rows where kernel and oracle differ most + 20 random ones
+    ev = np.nonzero(st != _lib.GF_ST_OUT_OF_PRIOR)[0]
+    pick = np.concatenate([ev[np.argsort(-np.nan_to_num(err[ev], nan=0.0))[:40]], rng.choice(ev, 20, replace=False)])
+    for i in pick:
+        ex = np.array([float(v) for v in mp_flux_avg(th[i], tuple(th[i, 6:10]), 3, src, BIN_EDGES)])
+        assert np.abs(fr[i] - ex).max() <= 1e-11, (i, th[i], fr[i], ex)
 
 
 # ---------------------------------------------------------------- full-size, size-independent properties

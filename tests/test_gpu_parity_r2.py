@@ -27,13 +27,32 @@ pytestmark = pytest.mark.gpu
 REL = 1e-10
 ABS_FR = 1e-10
 EXACT_FR = 1e-11
-# Rows whose unitarity verdict must equal the reference's: everything outside this band of the reference's own residual
-# around its threshold 1e-7 (fr.py:493-494).  Inside, the verdict is decided by last-bit rounding.
-UNI_BAND = (1e-9, 1e-5)
+# Rows whose unitarity verdict must equal the reference's: everything outside this band -- half a decade in all -- of the
+# 80-bit residual around the reference's threshold 1e-7 (fr.py:493-494).  The device replays the reference's operations
+# in emulated x87 arithmetic (gf_x87.hpp); inside the band a last-bit difference in asinl / acosl / sinl / cosl between
+# the emulation and glibc may still flip the verdict.
+UNI_BAND = (10 ** -7.25, 10 ** -6.75)
+# ... and for rows where the generating numpy's vectorised 10**logLam is not libm's (one fp64 ulp, ~5 % of rows: the
+# reference's own residual changes by a factor of order one with it, test_oracle_golden.py G17) the old, wide band
+UNI_BAND_WIDE = (1e-9, 1e-5)
 
 
-def _decided(r80):
-    return (r80 < UNI_BAND[0]) | (r80 > UNI_BAND[1])
+def _decided(r80, wide=None):
+    narrow = (r80 < UNI_BAND[0]) | (r80 > UNI_BAND[1])
+    if wide is None:
+        return narrow
+    return np.where(wide, (r80 < UNI_BAND_WIDE[0]) | (r80 > UNI_BAND_WIDE[1]), narrow)
+
+
+def _verdicts(st, r80, ref_st, evaluated):
+    """Unitarity verdict of the device on the evaluated rows: the oracle's (its residual `r80` against 1e-7, fr.py:493-494;
+    the oracle is the reference bit for bit given the same 10**logLam) outside the narrow band, and the reference's own
+    stored verdict outside the wide one."""
+    flagged = st == _lib.GF_ST_NON_UNITARY
+    dec = _decided(r80) & evaluated
+    assert np.array_equal(flagged[dec], (r80 >= 1e-7)[dec])
+    wide = ((r80 < UNI_BAND_WIDE[0]) | (r80 > UNI_BAND_WIDE[1])) & evaluated
+    assert np.array_equal(flagged[wide], (ref_st == 2)[wide])
 
 
 def _check_fr(fr, st, ref_fr, ref_st, exact, r80):
@@ -66,8 +85,7 @@ def test_bsm_golden_flux_average_dims_4_5_7_8(golden, oracle):
             fr, st = m.propagate(th)
         r80 = oracle.unitarity_residual_batch(om, th)
         ref_st = golden["g11_status"][sel]
-        dec = _decided(r80)
-        assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[dec], (ref_st == 2)[dec])
+        _verdicts(st, r80, ref_st, np.ones(len(th), bool))
         g, c = _check_fr(fr, st, golden["g11_fr"][sel], ref_st, golden["g11_fr_exact"][sel], r80)
         ngood += g; nclean += c
         nflag += int(((st == _lib.GF_ST_NON_UNITARY) & (ref_st == 2)).sum())
@@ -91,8 +109,7 @@ def test_bsm_golden_lnprob_12dim_dims_4_5_7_8(golden, oracle):
         r80 = oracle.unitarity_residual_batch(om, th)
         inbox = st != _lib.GF_ST_OUT_OF_PRIOR
         assert np.array_equal(~inbox, ~np.isfinite(golden["g12_fr_exact"][sel][:, 0])) and np.isneginf(ref[~inbox]).all()
-        dec = _decided(r80) & inbox
-        assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[dec], (ref_st == 2)[dec])
+        _verdicts(st, r80, ref_st, inbox)
         exact = golden["g12_fr_exact"][sel]
         has = inbox & np.isfinite(exact[:, 0])
         assert np.abs(fr[has] - exact[has]).max() <= EXACT_FR
@@ -123,8 +140,7 @@ def test_bsm_texture_none_golden(golden, oracle):
             fr, st = m.propagate(th)
         r80 = oracle.unitarity_residual_batch(om, th)
         ref_st = golden["g13_status"][sel]
-        dec = _decided(r80)
-        assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[dec], (ref_st == 2)[dec])
+        _verdicts(st, r80, ref_st, np.ones(len(th), bool))
         g, c = _check_fr(fr, st, golden["g13_fr"][sel], ref_st, golden["g13_fr_exact"][sel], r80)
         ngood += g; nclean += c
     assert ngood >= 150 and nclean >= 60
@@ -144,8 +160,7 @@ def test_bsm_texture_none_golden(golden, oracle):
         r80 = oracle.unitarity_residual_batch(om, th)
         inbox = st != _lib.GF_ST_OUT_OF_PRIOR
         assert (~inbox).sum() == 1 and np.isneginf(lp[~inbox]).all() and np.isneginf(ref[~inbox]).all()
-        dec = _decided(r80) & inbox
-        assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[dec], (ref_st == 2)[dec])
+        _verdicts(st, r80, ref_st, inbox)
         exact = golden["g14_fr_exact"][sel]
         has = inbox & np.isfinite(exact[:, 0])
         assert np.abs(fr[has] - exact[has]).max() <= EXACT_FR
@@ -236,7 +251,7 @@ def test_mc_x_postprocessing_vs_golden(golden):
 def test_unitarity_verdict_through_the_transition(golden, oracle):
     """G17: 792 walkers swept through the transition of the reference's unitarity assert (fr.py:461-499) for the six
     operator dimensions and three textures, with the reference's own residual per walker.  The device verdict equals
-    the reference's on every walker whose reference residual is outside UNI_BAND."""
+    the reference's on every walker whose reference residual is outside UNI_BAND (half a decade around 1e-7)."""
     rows, ref, ref_st = golden["g17_rows"], golden["g17_residual"], golden["g17_status"]
     ndec = nband = nagree_band = 0
     for key in np.unique(rows[:, :2], axis=0):
@@ -248,10 +263,12 @@ def test_unitarity_verdict_through_the_transition(golden, oracle):
         th = np.ascontiguousarray(rows[sel][:, 2:])
         with Model(desc) as m:
             fr, st = m.propagate(th)
-        dec = _decided(ref[sel])
+        import math
+        other_pow = np.array([math.pow(10., x) for x in th[:, 6]]) != golden["g17_sc2"][sel]
+        dec = _decided(ref[sel], wide=other_pow)
         flagged = st == _lib.GF_ST_NON_UNITARY
         assert np.array_equal(flagged[dec], (ref_st[sel] == 2)[dec]), (dim, tex)
         ndec += int(dec.sum()); nband += int((~dec).sum())
         nagree_band += int((flagged == (ref_st[sel] == 2))[~dec].sum())
-    assert ndec >= 600 and nband >= 40
-    assert nagree_band >= 0.7 * nband
+    assert ndec >= 700 and nband >= 5
+    assert nagree_band >= 0.6 * nband
