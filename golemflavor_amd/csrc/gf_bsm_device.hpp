@@ -3,6 +3,12 @@
 #pragma once
 #include "gf_device.hpp"
 
+// Floating-point contraction only where the source writes one expression (a * b + c), not across statements: with the
+// compiler's default (`fast`) the back end fuses or not depending on how often a product is used elsewhere, and the
+// <CHECK_UNI = true> / <false> instances, the lanes-per-walker variants and the sampler's copy of this code would round
+// differently in the last bit.  They are required to agree bit for bit (tests).  Restored at the end of the file.
+#pragma clang fp contract(on)
+
 namespace gfdev {
 
 constexpr int TEX_NONE = 4;
@@ -12,7 +18,7 @@ constexpr int TEX_NONE = 4;
 // (walker, bin) pair is queued for the x87-faithful evaluation of gf_unitarity.hip, which decides.
 constexpr double UNI_EST_SCALE = 2048.0;
 constexpr double UNI_THRESHOLD = 1e-7 * UNI_EST_SCALE;    // estimate-only verdict
-constexpr double UNI_LO = 1e-9 * UNI_EST_SCALE;
+constexpr double UNI_LO = 1e-9 * UNI_EST_SCALE;            // defaults of GfBsm::uni_lo / uni_hi
 constexpr double UNI_HI = 1e-5 * UNI_EST_SCALE;
 // doubles of LDS a group of LPW lanes sharing one walker needs: [nb][3] compositions, LPW residuals, LPW bin masks
 #define GF_FGRP_DOUBLES(nb, lpw) (3 * (nb) + 2 * (lpw))
@@ -144,7 +150,7 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 // Optionally the reference's eigenvector form for the unitarity status.
 template <bool CHECK_UNI>
 __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
-                                           double p[3][3], double& residual, unsigned long long& amb, int kbin)
+                                           double p[3][3], double& residual, unsigned long long& amb, int kbin, double uni_lo)
 {
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
@@ -226,7 +232,7 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
         double rr = 2.0 * off;                                         // |sum|XX^+| - 3| with the trace at 3
         if (rr != rr) rr = gf_inf();                                   // NaN fails the reference's test too
         residual = fmax(residual, rr);
-        if (rr >= UNI_LO) amb |= 1ull << kbin;                         // this bin's verdict is not safe from the estimate
+        if (rr >= uni_lo) amb |= 1ull << kbin;                         // this bin's verdict is not safe from the estimate
     }
 }
 
@@ -278,7 +284,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
-        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual, amb, k);
+        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual, amb, k, tb->uni_lo);
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
         const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
         const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
@@ -340,3 +346,5 @@ __device__ __forceinline__ bool lnprior_tab(const double* ctab, const double* ro
 
 
 }  // namespace gfdev
+
+#pragma clang fp contract(fast)

@@ -496,6 +496,19 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
                     b.t2_re[3 * i + j] = (double)t2.real(); b.t2_im[3 * i + j] = (double)t2.imag();
                 }
         }
+        // Band of the fp64 estimate handed to the arbitration.  Measured over 5 210 transition-zone walkers of all 18
+        // (dimension, texture) pairs (tools/uni_estimate_spread.py, profiles/r02/uni_estimate_spread.txt):
+        // log10(estimate / x87 residual) has median +0.15 and spans [-2.0, +1.6] for operator dimensions 3-6 and
+        // [-2.0, +3.1] for dimensions 7-8, where the SM term falls below one fp64 ulp of the NP term and the fp64
+        // evaluation overestimates.  The band covers that with margin.  (GF_UNI_BAND_DECADES: symmetric override,
+        // diagnostics; 0 = estimate only.)
+        {
+            double lo_dec = 2.3, hi_dec = d->dimension >= 7 ? 3.4 : 2.3;
+            if (const char* e = std::getenv("GF_UNI_BAND_DECADES")) { const double v = std::atof(e); if (v >= 0.0 && v <= 12.0) lo_dec = hi_dec = v; }
+            b.uni_lo = 1e-7 * 2048.0 * std::pow(10.0, -lo_dec);
+            b.uni_hi = 1e-7 * 2048.0 * std::pow(10.0, hi_dec);
+            if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the fp64 estimate
+        }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order
         {
             const double z = 0. + 1e-9;                                            // fr.py:370

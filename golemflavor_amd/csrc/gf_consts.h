@@ -62,6 +62,9 @@ struct GfBsm {
     // smu: the SM matrix when its angles are not columns of theta (NuFIT default, fr.py:313,435).
     double npu_hi[18], npu_lo[18];
     double smu_hi[18], smu_lo[18];
+    // band of the fp64 residual estimate (in units of the estimate itself, i.e. 2^11 x the x87 residual) inside which
+    // a (walker, bin) pair goes to the arbitration; below uni_lo: unitary, at or above uni_hi: not
+    double uni_lo, uni_hi;
 };
 
 // Work queue of the unitarity arbitration: (walker, energy bin) pairs whose fp64 estimate of the reference's
