@@ -92,13 +92,13 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
             double val = -gf_inf();
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
-                double residual = 0.0;
-                unsigned long long amb = 0;
-                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, residual, amb, sub, fgrp);
+                UniAcc acc = {0.0, 0.0, 0ull};
+                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
+                const unsigned long long amb = acc.amb;
                 st = ST_OK;
                 if (CHECK_UNI) {
-                    if (tb->uni_lo < 0.0) fr[0] = residual * (1.0 / UNI_EST_SCALE);    // diagnostics (GF_UNI_DUMP): the estimate itself
-                    if (!(residual < tb->uni_hi)) st = ST_NON_UNITARY;
+                    if (tb->uni_lo < 0.0) fr[0] = acc.est_max * (1.0 / UNI_EST_SCALE);  // diagnostics (GF_UNI_DUMP): the estimate itself
+                    if (!(acc.clear_max < tb->uni_hi)) st = ST_NON_UNITARY;
                     else if (amb != 0 && sub == 0 && uq) {
                         // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
                         // walker counts as unitary.  Walker indices in the queue are those of the whole batch.

@@ -12,16 +12,28 @@
 namespace gfdev {
 
 constexpr int TEX_NONE = 4;
-// The unitarity residual of the reference (fr.py:489-494, threshold 1e-7) is x87 rounding noise; the kernels evaluate the
-// same eigenvector form in fp64, whose residual `rr` is that noise 2^11 times louder -- an ESTIMATE, good to about two
-// decades either way.  rr / 2^11 below UNI_LO: unitary for the reference too; above UNI_HI: not unitary; in between the
-// (walker, bin) pair is queued for the x87-faithful evaluation of gf_unitarity.hip, which decides.
+// The unitarity residual of the reference (fr.py:489-494, threshold 1e-7) is x87 rounding noise, amplified by the
+// cancellations of the eigenvector formula.  Three tiers decide a (walker, energy bin) pair:
+//  1. the weight `a` of the SM term in the trace-normalised Hamiltonian H' = a S' + t N'.  The amplification grows like
+//     1/a (the SM term is what lifts the zero eigenvalue of the NP term): over 30 000 pairs of every operator dimension
+//     and texture incl. random NP angles the 80-bit residual never exceeds 1.3e-19 / a (tools/uni_weight_bound.py,
+//     profiles/r02/uni_weight_bound.txt).  a >= uni_a_ok (1e-10; residual < 2e-9): unitary, nothing is evaluated --
+//     the whole low-scale bulk of a posterior costs nothing extra;
+//  2. else the same eigenvector form in fp64, whose residual `rr` is the noise 2^11 times louder: an ESTIMATE.  Where
+//     fp64 still resolves the SM term (a >= uni_a_lin = 1e-13) it is good to about two decades either way, below that
+//     it can overestimate without bound.  rr below uni_lo: unitary; rr above uni_hi in the resolved regime: not unitary;
+//  3. everything else is queued for the x87-faithful evaluation of gf_unitarity.hip, which decides.
+// The device sampler, which needs the verdict inside the kernel, stops at tier 2 (rr against the scaled threshold).
 constexpr double UNI_EST_SCALE = 2048.0;
 constexpr double UNI_THRESHOLD = 1e-7 * UNI_EST_SCALE;    // estimate-only verdict
-constexpr double UNI_LO = 1e-9 * UNI_EST_SCALE;            // defaults of GfBsm::uni_lo / uni_hi
-constexpr double UNI_HI = 1e-5 * UNI_EST_SCALE;
-// doubles of LDS a group of LPW lanes sharing one walker needs: [nb][3] compositions, LPW residuals, LPW bin masks
-#define GF_FGRP_DOUBLES(nb, lpw) (3 * (nb) + 2 * (lpw))
+// doubles of LDS a group of LPW lanes sharing one walker needs: [nb][3] compositions + 3 unitarity accumulators per lane
+#define GF_FGRP_DOUBLES(nb, lpw) (3 * (nb) + 3 * (lpw))
+
+struct UniAcc {
+    double est_max;             // largest estimate over the bins tier 1 did not clear
+    double clear_max;           // ... over those of them where the estimate may condemn (a >= uni_a_lin)
+    unsigned long long amb;     // bins whose estimate reaches uni_lo
+};
 
 struct Herm3 {          // 3x3 Hermitian: real diagonal + the three upper off-diagonals
     double d0, d1, d2;
@@ -150,7 +162,7 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 // Optionally the reference's eigenvector form for the unitarity status.
 template <bool CHECK_UNI>
 __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
-                                           double p[3][3], double& residual, unsigned long long& amb, int kbin, double uni_lo)
+                                           double p[3][3], UniAcc& acc, int kbin, const GfBsm* __restrict__ tb)
 {
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
@@ -191,7 +203,7 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
     p[2][1] = (1.0 - p[0][1]) - p[1][1];
     p[2][2] = (1.0 - p[0][2]) - p[1][2];
 
-    if (CHECK_UNI) {
+    if (CHECK_UNI && a < tb->uni_a_ok) {
         // fr.py:216-236 in fp64, then fr.py:489-494.  h10 = conj(h01) etc.
         const double E[3] = {E0, E1, E2};
         const double d2 = fma(a, Sn.d2, t * Nn.d2);
@@ -231,8 +243,9 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
                            fast_sqrt(fma(f12r, f12r, f12i * f12i));
         double rr = 2.0 * off;                                         // |sum|XX^+| - 3| with the trace at 3
         if (rr != rr) rr = gf_inf();                                   // NaN fails the reference's test too
-        residual = fmax(residual, rr);
-        if (rr >= uni_lo) amb |= 1ull << kbin;                         // this bin's verdict is not safe from the estimate
+        acc.est_max = fmax(acc.est_max, rr);
+        if (a >= tb->uni_a_lin) acc.clear_max = fmax(acc.clear_max, rr);
+        if (rr >= tb->uni_lo) acc.amb |= 1ull << kbin;                 // this bin's verdict is not safe from the estimate
     }
 }
 
@@ -246,8 +259,8 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
 // lanes.  The walker's critical path drops from nb bins to ceil(nb / LPW).
 template <bool CHECK_UNI, int LPW = 1>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
-                                             const double* row, double fr[3], double& residual, unsigned long long& amb,
-                                             int sub = 0, double* fgrp = nullptr)
+                                             const double* row, double fr[3], UniAcc& acc, int sub = 0,
+                                             double* fgrp = nullptr)
 {
     // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
     double c1r[3], c1i[3], c2r[3], c2i[3];
@@ -284,7 +297,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
-        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, residual, amb, k, tb->uni_lo);
+        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, acc, k, tb);
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
         const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
         const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
@@ -300,7 +313,11 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         }
     }
     if (LPW > 1) {
-        if (CHECK_UNI) { fgrp[3 * nb + sub] = residual; fgrp[3 * nb + LPW + sub] = __longlong_as_double((long long)amb); }
+        if (CHECK_UNI) {
+            fgrp[3 * nb + sub] = acc.est_max;
+            fgrp[3 * nb + LPW + sub] = acc.clear_max;
+            fgrp[3 * nb + 2 * LPW + sub] = __longlong_as_double((long long)acc.amb);
+        }
         // the lanes of a group sit in one wave: its LDS operations retire in order, the fence keeps the compiler honest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -312,8 +329,9 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         if (CHECK_UNI) {
 #pragma unroll
             for (int j = 0; j < LPW; ++j) {
-                residual = fmax(residual, fgrp[3 * nb + j]);
-                amb |= (unsigned long long)__double_as_longlong(fgrp[3 * nb + LPW + j]);
+                acc.est_max = fmax(acc.est_max, fgrp[3 * nb + j]);
+                acc.clear_max = fmax(acc.clear_max, fgrp[3 * nb + LPW + j]);
+                acc.amb |= (unsigned long long)__double_as_longlong(fgrp[3 * nb + 2 * LPW + j]);
             }
         }
     }

@@ -496,17 +496,23 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
                     b.t2_re[3 * i + j] = (double)t2.real(); b.t2_im[3 * i + j] = (double)t2.imag();
                 }
         }
-        // Band of the fp64 estimate handed to the arbitration.  Measured over 5 210 transition-zone walkers of all 18
-        // (dimension, texture) pairs (tools/uni_estimate_spread.py, profiles/r02/uni_estimate_spread.txt):
-        // log10(estimate / x87 residual) has median +0.15 and spans [-2.0, +1.6] for operator dimensions 3-6 and
-        // [-2.0, +3.1] for dimensions 7-8, where the SM term falls below one fp64 ulp of the NP term and the fp64
-        // evaluation overestimates.  The band covers that with margin.  (GF_UNI_BAND_DECADES: symmetric override,
-        // diagnostics; 0 = estimate only.)
+        // Unitarity tiers (gf_bsm_device.hpp).  Tier 1: SM weight a >= 1e-10 -> unitary (80-bit residual <= 1.3e-19 / a
+        // over 30 000 pairs, tools/uni_weight_bound.py).  Tier 2, the fp64 estimate: measured against the 80-bit residual
+        // over the transition zone of all 18 (dimension, texture) pairs (tools/uni_estimate_spread.py), log10(estimate /
+        // residual) spans [-2.3, +1.9] while fp64 resolves the SM term (a >= 1e-12) and [-4.0, +7.6] below -- there the
+        // estimate may only acquit (with margin), never condemn.  (GF_UNI_BAND_DECADES: symmetric override of the
+        // estimate's band, diagnostics; 0 = estimate only.)
         {
-            double lo_dec = 2.3, hi_dec = d->dimension >= 7 ? 3.4 : 2.3;
-            if (const char* e = std::getenv("GF_UNI_BAND_DECADES")) { const double v = std::atof(e); if (v >= 0.0 && v <= 12.0) lo_dec = hi_dec = v; }
+            double lo_dec = 4.5, hi_dec = 2.5;
+            b.uni_a_ok = 1e-10;
+            b.uni_a_lin = 1e-12;
+            if (const char* e = std::getenv("GF_UNI_BAND_DECADES")) {
+                const double v = std::atof(e);
+                if (v >= 0.0 && v <= 12.0) { lo_dec = hi_dec = v; if (v == 0.0) b.uni_a_lin = 0.0; }
+            }
             b.uni_lo = 1e-7 * 2048.0 * std::pow(10.0, -lo_dec);
             b.uni_hi = 1e-7 * 2048.0 * std::pow(10.0, hi_dec);
+            if (std::getenv("GF_UNI_NO_WEIGHT_GATE")) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
             if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the fp64 estimate
         }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order

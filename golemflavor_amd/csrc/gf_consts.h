@@ -62,8 +62,10 @@ struct GfBsm {
     // smu: the SM matrix when its angles are not columns of theta (NuFIT default, fr.py:313,435).
     double npu_hi[18], npu_lo[18];
     double smu_hi[18], smu_lo[18];
-    // band of the fp64 residual estimate (in units of the estimate itself, i.e. 2^11 x the x87 residual) inside which
-    // a (walker, bin) pair goes to the arbitration; below uni_lo: unitary, at or above uni_hi: not
+    // unitarity tiers (gf_bsm_device.hpp): SM weight at or above which a bin is unitary outright; SM weight at or above
+    // which the fp64 estimate may condemn a bin; the estimate (2^11 x the x87 residual) below which a bin is unitary and
+    // at or above which it is not
+    double uni_a_ok, uni_a_lin;
     double uni_lo, uni_hi;
 };
 

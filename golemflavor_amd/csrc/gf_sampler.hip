@@ -98,10 +98,9 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
         val = -gf_inf();
         st = ST_OUT_OF_PRIOR;
         if (inbox) {
-            double residual = 0.0;
-            unsigned long long amb = 0;
-            flux_average<true, LPW>(c, tb, ttab, row, fr, residual, amb, sub, fgrp);
-            st = (residual < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;
+            UniAcc acc = {0.0, 0.0, 0ull};
+            flux_average<true, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
+            st = (acc.est_max < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;      // tiers 1 and 2 (gf_bsm_device.hpp)
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;
         }

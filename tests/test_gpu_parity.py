@@ -308,8 +308,18 @@ def test_bsm_random_vs_oracle(oracle, dim, tex):
     # walker.  (Checked against 60-digit arithmetic: where the two differ by more than 1e-10 it is the
     # 80-bit closed form that is off, e.g. dim 7, logLam = -38: oracle 1e-8 from exact, kernel 4e-15.)
     r80 = oracle.unitarity_residual_batch(om, th)
-    tol = ABS_FR + 10.0 * r80            # measured worst ratio error / defect: 7 (tools/diag_bsm_r80.py)
-    assert np.all(np.abs(fr[good] - ref_fr[good]).max(axis=1) <= tol[good])
+    tol = ABS_FR + 10.0 * r80            # typical worst ratio error / defect: 7 (tools/diag_bsm_r80.py)
+    err = np.abs(fr - ref_fr).max(axis=1)
+    over = np.flatnonzero(good & (err > tol))
+    if over.size:
+        # just under the reference's own threshold (r80 approaching 1e-7) the 80-bit closed form can be off by more than
+        # ten times its unitarity defect: arbitrate with 60-digit arithmetic -- the kernel must be the accurate one
+        from exact_mp import exact_flux_avg
+        assert over.size <= 0.005 * good.sum(), (over.size, good.sum())
+        pick = over[np.argsort(err[over])[::-1][:8]]
+        exact = exact_flux_avg(th[pick], tex.name, dim, src, BIN_EDGES)
+        assert np.abs(fr[pick] - exact).max() <= 1e-11
+        assert np.all(np.abs(ref_fr[pick] - exact).max(axis=1) > np.abs(fr[pick] - exact).max(axis=1))
     clean = good & (r80 < 1e-13)
     assert clean.sum() > 2000
     assert np.abs(fr[clean] - ref_fr[clean]).max() <= ABS_FR
