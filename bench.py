@@ -13,13 +13,20 @@ timed region starts.  A "step" is one pass of the hot path (one kernel launch) o
 N > 1: one process per GPU.  Ensembles (independent chains) shard across ranks with no data-path
 collective (weak scaling: every rank evaluates `--ensembles` ensembles).  RCCL (through the
 library's own gf_comm_* C ABI) broadcasts the packed model descriptor from rank 0 before the
-timed region and all-gathers one chain block per rank after it; host-side control (barrier,
-max-over-ranks) goes through torch.distributed/gloo.
+timed region and all-gathers one chain block per rank after it; host-side control (rendezvous, barrier,
+max-over-ranks, the RCCL id) runs over plain TCP sockets (golemflavor_amd.dist.SocketBackend) -- there is no
+PyTorch in this process, so the ROCm runtime and librccl it maps are always /opt/rocm's (the path is in the line).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant (only) kernel: algorithmic bytes
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant (only) kernel of the timed region: algorithmic bytes
 (56 B per evaluation: 6 x 8 B read + 8 B written) over the average launch duration measured with
 HIP events on the stream the kernel runs on.  `cpu_baseline` is the CPU oracle (oracle/, a
 long-double restatement of the reference, kind "port") timed on this host on a bounded sample.
+
+After the timed region (N = 1 only; `--no-extras` skips them) the other BASELINE configurations are measured too,
+each bounded to a few seconds, as sub-records of the same line: `c3` (1e7 Haar draws), `c4_bulk` / `c5_bulk` (the
+7- / 12-column flux-averaged posterior kernel with and without the unitarity status), `c4_scan` / `c5_scan` (the full
+64 x 2048 and 256 x 512 grid scans through the device sampler, by phase), `emcee_driven` (one 4096-walker ensemble)
+and `emcee_driven_c1_scaling` (100-walker chains, the metric's own wording, x {1, 16, 256, 4096}).
 """
 import argparse
 import ctypes as C
@@ -36,12 +43,15 @@ if ROOT not in sys.path:
 
 from golemflavor_amd import _lib  # noqa: E402
 from golemflavor_amd import configs as Cf  # noqa: E402
+from golemflavor_amd import dist as gdist  # noqa: E402
 from golemflavor_amd import fr as fr_utils  # noqa: E402
 from golemflavor_amd.descriptor import compile_model  # noqa: E402
+from golemflavor_amd.enums import Texture  # noqa: E402
 from golemflavor_amd.model import Model  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_EVAL = 6 * 8 + 8     # 8*ndim read + 8 written, no fr / status blob
+FP64_ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one fp64 VALU instruction per 4 cycles at 2.4 GHz
 
 
 def parse():
@@ -52,7 +62,8 @@ def parse():
     ap.add_argument("--walkers", type=int, default=4096, help="walkers per ensemble (BASELINE config 2)")
     ap.add_argument("--ensembles", type=int, default=4096, help="independent ensembles stacked per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sampler", action="store_true", help="skip the emcee-driven extra (profiling runs)")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the emcee-driven extras (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3 / C4 / C5 sub-records (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="evaluations in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -103,16 +114,177 @@ def cpu_baseline(ps, bf, theta, sample):
             "sample": "%d evaluations of the bench theta batch, oracle/golem_oracle.c (long double), %d threads; "
                       "single-thread rate %.3g evals/s on %d evaluations" % (n, cores, rate1, len(th1)),
             "single_thread_value": rate1,
-            "reference_python_evals_per_s_1core_build_container": ref_rate}, ref
+            "reference_python_evals_per_s_1core_build_container": ref_rate,
+            "note": "the reference's own rate was timed in the build container (another machine): "
+                    "gpu_over_reference_python_1core compares across machines"}, ref
 
 
 def _claim_stdout():
-    """Keep fd 1 clean for the ONE JSON line: gloo and RCCL print banners to the C-level stdout, so
+    """Keep fd 1 clean for the ONE JSON line: RCCL prints banners to the C-level stdout, so
     everything else in this process is pointed at stderr; returns the stream the JSON line goes to."""
     sys.stdout.flush()
     keep = os.dup(1)
     os.dup2(2, 1)
     return os.fdopen(keep, "w")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sub-records: the other BASELINE configurations, device-resident, HIP-event timed, each a few seconds at most
+def _timed(model, fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = model.event(), model.event()
+    model.sync()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    model.sync()
+    return e0.elapsed_ms(e1) / reps
+
+
+def _profile_constants():
+    """Per-bin VALU instruction counts of the flux-averaged kernel, from the committed rocprofv3 SQ_INSTS_VALU pass
+    (profiles/bsm_instr.json, regenerated by profiles/run_profile_bsm.sh): they turn a rate into a fraction of the
+    fp64 issue rate.  None when the file is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "bsm_instr.json")))
+    except Exception:
+        return None
+
+
+def extra_c3(device):
+    """C3: scripts/mc_unitary.py -- 1e7 Haar draws propagated, output resident on the device (24 B written per draw)."""
+    n = 10_000_000
+    with Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1 / 3, 2 / 3, 0.0)), device=device) as m:
+        d_fr = m.alloc(24 * n)
+        ms = _timed(m, lambda: m.haar_draw_device(26, 0, n, None, d_fr.ptr), reps=50)
+        d_ang = m.alloc(32 * n)
+        ms_a = _timed(m, lambda: m.haar_draw_device(26, 0, n, d_ang.ptr, d_fr.ptr), reps=30)
+    return {"workload": "gf_haar_draw_device, 1e7 draws per launch (seed 26), composition only / + the 4 angles",
+            "draws": n, "kernel_ms": ms, "draws_per_s": n / ms * 1e3, "bytes_per_draw": 24,
+            "GBps_algorithmic": 24 * n / ms / 1e6, "frac_of_hbm_peak": 24 * n / ms / 1e6 / HBM_PEAK_GBS,
+            "with_angles": {"kernel_ms": ms_a, "draws_per_s": n / ms_a * 1e3, "bytes_per_draw": 56,
+                            "frac_of_hbm_peak": 56 * n / ms_a / 1e6 / HBM_PEAK_GBS},
+            "bound": "integer VALU (two Philox4x32-10 blocks per draw), not HBM"}
+
+
+def extra_bulk(device, ps, label, n=4 * 1024 * 1024):
+    """C4 / C5 bulk: the flux-averaged (20-bin) posterior kernel on n walkers, theta ~ U(seed box), logLam ~ U over the
+    scale range less its top 6 decades (dimension 6, texture OET, source (0,1,0)), with and without the status array."""
+    dim, tex = 6, Texture.OET
+    rng = np.random.default_rng(1)
+    box = np.array(ps.seeds, dtype=float)
+    th = rng.uniform(box[:, 0], box[:, 1], size=(n, len(ps)))
+    lo, hi = Cf.SCALE_BOUNDARIES[dim]
+    th[:, -1] = rng.uniform(lo, hi - 6, n)
+    desc = compile_model(ps, "BSM_GAUSS", texture=tex, dimension=dim, binning=Cf.default_bin_edges(), source_ratio=(0., 1., 0.),
+                         bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    out = {"workload": "%s: %d-column flux_averaged_BSMu posterior, %d walkers per launch, 20 energy bins, dimension 6, OET"
+                       % (label, len(ps), n), "n": n, "nbins": 20}
+    consts = _profile_constants()
+    with Model(desc, device=device) as m:
+        d_th = m.alloc(th.nbytes).upload(th)
+        d_out, d_st = m.alloc(8 * n), m.alloc(4 * n)
+        for key, st in (("no_status", None), ("with_status", d_st.ptr)):
+            ms = _timed(m, lambda: m.lnprob_device(d_th.ptr, n, d_out.ptr, None, st), reps=20)
+            rec = {"kernel_ms": ms, "evals_per_s": n / ms * 1e3, "bin_diag_per_s": 20 * n / ms * 1e3,
+                   "GBps_algorithmic": n * (8 * len(ps) + 8 + (4 if st else 0)) / ms / 1e6}
+            rec["frac_of_hbm_peak"] = rec["GBps_algorithmic"] / HBM_PEAK_GBS
+            ipw = (consts or {}).get("%d_%s" % (len(ps), key), {}).get("valu_wave_instr_per_walker")
+            if ipw:
+                # wave-instructions retired per second over what 1024 SIMDs can issue (one fp64 instruction per 4 cycles)
+                rec["valu_instr_per_walker"] = ipw
+                rec["fp64_issue_fraction"] = (n / 64.0) * ipw / (ms * 1e-3) / FP64_ISSUE_PER_S
+            out[key] = rec
+        # where the unitarity verdict is not free: logLam over the FULL range of a texture that fails at its top (OEU)
+        th[:, -1] = rng.uniform(lo, hi, n)
+        desc2 = compile_model(ps, "BSM_GAUSS", texture=Texture.OEU, dimension=dim, binning=Cf.default_bin_edges(),
+                              source_ratio=(0., 1., 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    with Model(desc2, device=device) as m:
+        n2 = n // 4
+        d_th = m.alloc(th[:n2].nbytes).upload(th[:n2])
+        d_out, d_st = m.alloc(8 * n2), m.alloc(4 * n2)
+        ms = _timed(m, lambda: m.lnprob_device(d_th.ptr, n2, d_out.ptr, None, d_st.ptr), reps=3, warm=1)
+        st = d_st.download((n2,), dtype=np.int32)
+        out["with_status_through_the_failing_region"] = {
+            "workload": "texture OEU, logLam over its whole range (the top fails the reference's unitarity assert): every "
+                        "undecided (walker, bin) is re-evaluated in emulated x87 arithmetic", "n": n2, "kernel_ms": ms,
+            "evals_per_s": n2 / ms * 1e3, "nonunitary_fraction": float(np.mean(st == 2))}
+    out["bound"] = "fp64 VALU issue / dependency latency (HBM fraction << 1)"
+    return out
+
+
+def extra_scan(device, config):
+    """C4 / C5 end to end at full size: stacked device sampler (100 burn-in + 200 stored steps), post-processing (C4),
+    chains to the host -- golemflavor_amd.scan's own code path on one rank."""
+    from golemflavor_amd import scan
+    t0 = time.perf_counter()
+    if config == "C4":
+        pts = scan.texture_grid(6)
+        nw = 2048
+        make = lambda p, g: scan._TexturePoint(p, g, dimension=6, texture=Texture.OET, nwalkers=nw, device=device)  # noqa: E731
+        evals = nw * 300 + nw * 200
+    else:
+        pts = scan.sens_grid()
+        nw = 512
+        make = lambda p, g: scan._SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
+        evals = nw * 300
+    stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
+    chains = scan.run_points(pts, list(range(len(pts))), make, 100, 200, stacked=True,
+                             gather=scan.DeviceGather(None, 0, 1, stage))
+    stage.close()
+    dt = time.perf_counter() - t0
+    nbytes = sum(c.nbytes for c in chains)
+    return {"workload": "%s: %d grid points x %d walkers, 100 burn-in + 200 stored steps, one stacked sampler" % (config, len(pts), nw),
+            "grid_points": len(pts), "walkers": nw, "seconds": dt, "phases": {k: round(v, 4) for k, v in scan.PHASES.items()},
+            "evals": len(pts) * evals, "evals_per_s": len(pts) * evals / dt, "chain_bytes_to_host": nbytes,
+            "sampling_evals_per_s": len(pts) * nw * 300 / max(scan.PHASES.get("sampling", dt), 1e-9),
+            "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}
+
+
+def extra_emcee(model, ps, walkers):
+    """emcee-driven figures (never `value`): the device-resident stretch move."""
+    from golemflavor_amd import mcmc as mcmc_utils
+    out = {}
+    rngp = np.random.default_rng(26)
+    box = np.array(ps.seeds, dtype=np.float64)
+    p0 = rngp.uniform(box[:, 0], box[:, 1], size=(walkers, 6))
+    smp = mcmc_utils.DeviceEnsembleSampler(walkers, 6, model, seed=26)
+    smp.run_mcmc(p0, 50, storechain=False)
+    t0 = time.perf_counter()
+    smp.run_mcmc(None, 500, storechain=False)
+    dt = time.perf_counter() - t0
+    out["emcee_driven"] = {"sampler": "device-resident stretch move", "walkers": walkers, "chains": 1,
+                           "steps": 500, "us_per_step": 1e6 * dt / 500, "evals_per_s": walkers * 500 / dt,
+                           "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
+    smp.close()
+    # BASELINE.json's metric as worded -- 100-walker chains (configs[0]) -- one workgroup per ensemble, walkers in LDS,
+    # a run is one launch.  One chain is ONE wave's dependent-instruction chain: a latency, not a throughput; chains side
+    # by side fill the machine.  Model: t_step(k chains) = max(L1, k / R_inf), L1 = the single-chain step latency,
+    # R_inf = chain-steps per second with every CU busy.
+    rows = []
+    for nch, steps in ((1, 20000), (16, 20000), (256, 4000), (4096, 600)):
+        p1 = rngp.uniform(box[:, 0], box[:, 1], size=(nch, 100, 6))
+        smp = mcmc_utils.DeviceEnsembleSampler(100, 6, model, nchains=nch, seed=26)
+        smp.run_mcmc(p1 if nch > 1 else p1[0], 100, storechain=False)
+        t0 = time.perf_counter()
+        smp.run_mcmc(None, steps, storechain=False)
+        dt = time.perf_counter() - t0
+        rows.append({"chains": nch, "steps": steps, "us_per_step": 1e6 * dt / steps, "evals_per_s": 100.0 * nch * steps / dt,
+                     "acceptance_fraction": float(np.mean(smp.acceptance_fraction))})
+        smp.close()
+    l1 = rows[0]["us_per_step"]
+    rinf = rows[-1]["chains"] / (rows[-1]["us_per_step"] * 1e-6)
+    for r in rows:
+        r["model_us_per_step"] = max(l1, r["chains"] / rinf * 1e6)
+    out["emcee_driven_c1_scaling"] = {
+        "sampler": "device-resident stretch move, one workgroup per 100-walker ensemble (k_stretch_persist)",
+        "rows": rows, "single_chain_step_latency_us": l1, "chain_steps_per_s_saturated": rinf,
+        "model": "us_per_step(k) = max(L1, k / R_inf): one chain is bound by one wave's dependent instructions "
+                 "(~%.0f us per step at 2 half-steps), %d chains by the machine's throughput" % (l1, rows[-1]["chains"]),
+        "evals_per_s_1_chain": rows[0]["evals_per_s"], "evals_per_s_saturated": rows[-1]["evals_per_s"]}
+    return out
 
 
 def main():
@@ -125,69 +297,18 @@ def main():
         local_rank = int(os.environ["GF_BENCH_DEVICE"])
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    dist = None
-    comm = None
-    rccl_error = None
-    hard_exit = False          # a stuck RCCL bootstrap thread would block interpreter shutdown
-    L = _lib.lib()
+    L = _lib.lib()                           # libgolemhip.so (and with it /opt/rocm's runtime + librccl) before anything else ROCm
+    control = gdist.SocketBackend(rank, world) if world > 1 else gdist.LocalBackend()
+    rccl, rccl_error, stuck = None, None, False
     ps, bf, desc = notebook_descriptor()
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        # RCCL communicator of the library itself: unique id travels over the gloo store.  The timed
-        # region has no collective, so an RCCL problem must not cost the measurement: fall back to gloo
-        # for the descriptor broadcast and report the failure in the JSON line.
-        rccl_error = None
-        box = {}
-
-        def _rccl_setup():
-            try:
-                h = C.c_void_p()
-                _lib.check(L.gf_comm_create(idb, rank, world, local_rank, C.byref(h)), "gf_comm_create")
-                box["comm"] = h
-                # fixed physics constants: rank 0's packed descriptor is the one everybody uses
-                raw = (C.c_uint8 * C.sizeof(desc)).from_buffer(desc)
-                _lib.check(L.gf_comm_broadcast(h, raw, C.sizeof(desc), 0), "gf_comm_broadcast")
-                box["ok"] = True
-            except Exception as exc:       # noqa: BLE001
-                box["err"] = "%s: %s" % (type(exc).__name__, exc)
-
-        try:
-            ids = [None]
-            if rank == 0:
-                buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
-                _lib.check(L.gf_comm_unique_id(buf), "gf_comm_unique_id")
-                ids = [bytes(buf)]
-            dist.broadcast_object_list(ids, src=0)
-            idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(ids[0])
-            # a communicator that cannot bootstrap must not hang the measurement: bounded wait
-            import threading
-            th = threading.Thread(target=_rccl_setup, daemon=True)
-            th.start()
-            th.join(timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
-            if th.is_alive():
-                rccl_error = "timeout: RCCL communicator setup did not finish"
-                hard_exit = True
-            elif "err" in box:
-                rccl_error = box["err"]
-            else:
-                comm = box["comm"]
-        except Exception as exc:           # noqa: BLE001
-            rccl_error = "%s: %s" % (type(exc).__name__, exc)
-            comm = None
-        flags = [rccl_error]
-        gathered = [None] * world
-        dist.all_gather_object(gathered, rccl_error)
-        if any(g is not None for g in gathered):
-            rccl_error = next(g for g in gathered if g is not None)
-            if comm is not None:
-                L.gf_comm_destroy(comm)
-                comm = None
-            blob = [bytes(memoryview(desc))] if rank == 0 else [None]
-            dist.broadcast_object_list(blob, src=0)
-            desc = _lib.GfModelDesc.from_buffer_copy(blob[0])
+        # RCCL communicator of the library itself; its unique id travels over the socket control plane.  The timed
+        # region has no collective, so an RCCL problem must not cost the measurement: the descriptor then goes over the
+        # control plane, the failure is reported in the JSON line AND in the exit status.
+        rccl, rccl_error, stuck = gdist.open_rccl(rank, world, local_rank, control,
+                                                  timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+        # fixed physics constants: rank 0's packed descriptor is the one everybody uses
+        desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if rccl is not None else control)[0]
 
     n = a.walkers * a.ensembles
     model = Model(desc, device=local_rank)
@@ -200,8 +321,7 @@ def main():
 
     def fence():
         model.sync()
-        if dist is not None:
-            dist.barrier()
+        control.barrier()
         model.sync()
 
     for _ in range(a.warmup):
@@ -217,39 +337,39 @@ def main():
     elapsed = time.perf_counter() - t0                 # ... at this instant; the MAX over ranks below is the job's time
     fence()                                            # closing bracket: barrier + synchronize (its latency is not a step)
     kernel_ms = ev0.elapsed_ms(ev1) / a.steps          # average launch duration on the kernel's stream
+    elapsed, kernel_ms = [float(x) for x in control.allreduce_max([elapsed, kernel_ms])]
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-
-    # after the timed region: gather one chain block (the first ensemble's lnprob) from every rank
+    # after the timed region: gather one chain block (the first ensemble's lnprob) from every rank over RCCL
     gathered_ok = None
-    if comm is not None:
+    if rccl is not None:
         try:
             blk = 8 * a.walkers
             d_all = model.alloc(blk * world)
-            _lib.check(L.gf_comm_allgather(comm, d_out.ptr, d_all.ptr, blk), "gf_comm_allgather")
+            rccl.allgather_device(d_out.ptr, d_all.ptr, blk)
             allv = d_all.download((world, a.walkers))
             mine = d_out.download((a.walkers,))
             gathered_ok = bool(np.array_equal(allv[rank], mine, equal_nan=True))
         except Exception as exc:           # noqa: BLE001
             rccl_error = "%s: %s" % (type(exc).__name__, exc)
             gathered_ok = False
+        oks = control.allgather_bytes(b"1" if gathered_ok else b"0")
+        gathered_ok = all(x == b"1" for x in oks)
 
     if rank == 0:
         evals = float(n) * a.steps * world
         value = evals / elapsed
         ach = BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the PMC pass committed under profiles/ (same command, same n)
-        traffic = None
+        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (they cannot be read
+        # inside this run); the number below is the one of the committed pass of this same command and batch size
+        # (profiles/traffic.json, regenerated by profiles/run_profile.sh), null when that file does not match
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
                 if int(tj.get("n", -1)) == n:
                     traffic = tj.get("traffic_bytes_per_launch")
+                    traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run)"
             except Exception:
                 traffic = None
         metric = "walker-lnprob evals/sec (Gaussian llh, 100 walkers) at 1/2/4/8 MI355X"
@@ -267,48 +387,33 @@ def main():
                        "walkers_per_ensemble": a.walkers, "ensembles_per_launch_per_gpu": a.ensembles,
                        "evals_per_step_per_gpu": n, "ndim": 6, "parallelism": "independent ensembles sharded over %d GPU(s)" % world,
                        "note": "BASELINE.json words the metric on its configs[0] (100-walker chain, CPU plumbing); the bench line "
-                               "is configs[1], 4096-walker ensembles on the GPU; the 100-walker chain itself is in emcee_driven_c1"},
+                               "is configs[1], 4096-walker ensembles on the GPU; the 100-walker chains themselves are in "
+                               "emcee_driven_c1_scaling"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
                          "kernel": "k_lnprob_sm_fast<6, SM_GAUSS, canonical, no fr>"},
+            "control_plane": "tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
+            "librccl": gdist.rccl_library_info(),
         }
         if gathered_ok is not None:
             out["rccl_gather_ok"] = gathered_ok
         if rccl_error is not None:
             out["rccl_error"] = rccl_error
         if world == 1 and not a.no_sampler:
-            # emcee-driven figure (not `value`): one 4096-walker ensemble advanced by the device-resident
-            # stretch-move sampler, 2 launches per step, walkers never leave HBM
             try:
-                from golemflavor_amd import mcmc as mcmc_utils
-                rngp = np.random.default_rng(26)
-                box = np.array(ps.seeds, dtype=np.float64)
-                p0 = rngp.uniform(box[:, 0], box[:, 1], size=(a.walkers, 6))
-                smp = mcmc_utils.DeviceEnsembleSampler(a.walkers, 6, model, seed=26)
-                smp.run_mcmc(p0, 50, storechain=False)
-                t0 = time.perf_counter()
-                smp.run_mcmc(None, 500, storechain=False)
-                dt = time.perf_counter() - t0
-                out["emcee_driven"] = {"sampler": "device-resident stretch move", "walkers": a.walkers, "chains": 1,
-                                       "steps": 500, "us_per_step": 1e6 * dt / 500, "evals_per_s": a.walkers * 500 / dt,
-                                       "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
-                smp.close()
-                # configs[0] as written: ONE 100-walker chain (one workgroup, walkers in LDS, the run is one launch),
-                # and 256 such chains side by side
-                for key, nch, steps in (("emcee_driven_c1", 1, 20000), ("emcee_driven_c1_x256", 256, 4000)):
-                    p1 = rngp.uniform(box[:, 0], box[:, 1], size=(nch, 100, 6))
-                    smp = mcmc_utils.DeviceEnsembleSampler(100, 6, model, nchains=nch, seed=26)
-                    smp.run_mcmc(p1 if nch > 1 else p1[0], 100, storechain=False)
-                    t0 = time.perf_counter()
-                    smp.run_mcmc(None, steps, storechain=False)
-                    dt = time.perf_counter() - t0
-                    out[key] = {"sampler": "device-resident stretch move, one workgroup per ensemble", "walkers": 100,
-                                "chains": nch, "steps": steps, "us_per_step": 1e6 * dt / steps,
-                                "evals_per_s": 100.0 * nch * steps / dt,
-                                "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
-                    smp.close()
+                out.update(extra_emcee(model, ps, a.walkers))
             except Exception as exc:       # noqa: BLE001
                 out["emcee_driven"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if world == 1 and not a.no_extras:
+            for key, fn in (("c3", lambda: extra_c3(local_rank)),
+                            ("c4_bulk", lambda: extra_bulk(local_rank, Cf.texture_paramset(6), "C4")),
+                            ("c5_bulk", lambda: extra_bulk(local_rank, Cf.fr_paramsets(6, (0.4444, 0.0))[1], "C5")),
+                            ("c4_scan", lambda: extra_scan(local_rank, "C4")),
+                            ("c5_scan", lambda: extra_scan(local_rank, "C5"))):
+                try:
+                    out[key] = fn()
+                except Exception as exc:   # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not a.no_cpu_baseline:
             cb, ref = cpu_baseline(ps, bf, theta, a.cpu_sample)
             got = d_out.download((len(ref),))
@@ -322,15 +427,21 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 
-    if comm is not None:
-        L.gf_comm_destroy(comm)
+    if rccl is not None:
+        rccl.close()
     model.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if hard_exit:
+    try:
+        control.barrier()
+    except Exception:                      # noqa: BLE001
+        pass
+    control.close()
+    if rccl_error is not None:
+        # the measurement is complete and printed; a broken RCCL path still fails the command
+        sys.stderr.write("bench.py: RCCL problem: %s\n" % rccl_error)
         sys.stderr.flush()
-        os._exit(0)
+        if stuck:
+            os._exit(3)                    # a helper thread is still inside ncclCommInitRank: it would block a normal exit
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -103,6 +103,12 @@ SIGNATURES = {
     "gf_comm_broadcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "gf_comm_allgather": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gf_comm_barrier": (C.c_int, [_vp]),
+    "gf_comm_last_error": (C.c_char_p, []),
+    "gf_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "gf_host_prepare": (C.c_int, [_vp, C.c_size_t]),
+    "gf_sampler_set_stream_ids": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "gf_sampler_get_chain_device": (C.c_int, [_vp, _vp, _vp]),
+    "gf_sampler_postprocess_device": (C.c_int, [_vp, C.POINTER(_vp), _vp, _vp]),
 }
 
 _lib = None
@@ -138,6 +144,8 @@ def check(code, what=""):
         L = lib()
         msg = L.gf_strerror(code).decode()
         detail = L.gf_last_hip_error().decode()
+        if code == GF_ERR_COMM and not detail:
+            detail = L.gf_comm_last_error().decode()
         raise GolemHipError(code, "%s failed: %s%s" % (what or "libgolemhip call", msg,
                                                      (" [" + detail + "]") if detail else ""))
 

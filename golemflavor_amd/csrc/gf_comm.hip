@@ -14,6 +14,8 @@
 
 static_assert(GF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RCCL unique id size changed");
 
+extern "C" void gf_internal_set_error(const char* msg);   // gf_capi.hip
+
 struct gf_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
@@ -25,6 +27,7 @@ thread_local char g_cerr[256] = "";
 int comm_fail(const char* what, const char* msg)
 {
     std::snprintf(g_cerr, sizeof(g_cerr), "%s: %s", what, msg);
+    gf_internal_set_error(g_cerr);          // one thread-local error text for the whole library: gf_last_hip_error()
     return GF_ERR_COMM;
 }
 #define GF_NCCL(call)                                                        \
@@ -42,6 +45,29 @@ int comm_fail(const char* what, const char* msg)
 extern "C" {
 
 const char* gf_comm_last_error(void) { return g_cerr; }
+
+// "<version code> <path of the loaded librccl>": which RCCL this process actually runs on (a process that imported
+// PyTorch first may have mapped torch's bundled copy under the same soname)
+int gf_comm_library_info(char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return GF_ERR_INVALID_ARG;
+    int ver = 0;
+    (void)ncclGetVersion(&ver);
+    char path[512] = "?";
+    if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+        char line[1024];
+        while (std::fgets(line, sizeof(line), f)) {
+            const char* p = std::strstr(line, "librccl");
+            if (!p) continue;
+            const char* q = std::strchr(line, '/');
+            if (q) { std::snprintf(path, sizeof(path), "%s", q); path[std::strcspn(path, "\n")] = 0; }
+            break;
+        }
+        std::fclose(f);
+    }
+    std::snprintf(buf, buflen, "%d %s", ver, path);
+    return GF_OK;
+}
 
 int gf_comm_unique_id(uint8_t id[GF_COMM_ID_BYTES])
 {
@@ -94,10 +120,14 @@ int gf_comm_broadcast(gf_comm* c, void* host_buf, size_t bytes, int root)
     int rc = GF_OK;
     hipError_t e = hipSuccess;
     if (c->rank == root) e = hipMemcpyAsync(d, host_buf, bytes, hipMemcpyHostToDevice, c->stream);
-    ncclResult_t r = ncclSuccess;
-    if (e == hipSuccess) r = ncclBroadcast(d, d, bytes, ncclChar, root, c->comm, c->stream);
-    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(host_buf, d, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    // every rank enters the collective whatever its local copy did: a root that skipped it would leave the others
+    // blocked inside ncclBroadcast; the copy error is reported after the exchange
+    const hipError_t e_copy = e;
+    ncclResult_t r = ncclBroadcast(d, d, bytes, ncclChar, root, c->comm, c->stream);
+    e = hipSuccess;
+    if (r == ncclSuccess) e = hipMemcpyAsync(host_buf, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (r == ncclSuccess && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = e_copy;
     if (r != ncclSuccess) rc = comm_fail("ncclBroadcast", ncclGetErrorString(r));
     else if (e != hipSuccess) rc = comm_fail("gf_comm_broadcast", hipGetErrorString(e));
     (void)hipFree(d);

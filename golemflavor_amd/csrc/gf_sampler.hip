@@ -77,6 +77,10 @@ struct StretchArgs {
     const double* const* ptabs;
     int32_t nbins_max;      // largest nbins over the chains' models (BSM); sizes the lane-group buffers
     int32_t lpw;            // lanes per walker for this run (host-side dispatch only)
+    // random stream of chain ch: Philox counter word = stream_ids[ch] * (nwalkers / 2) + walker slot.  NULL: ch itself.
+    // A scan hands in the GLOBAL grid index, so that a grid point's chain does not depend on which rank runs it or on
+    // how many other points share its sampler.
+    const uint64_t* stream_ids;
 };
 
 __global__ void k_tick(StepState* st, int nsteps)
@@ -144,7 +148,8 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
     const bool store_now = s.state->store != 0 && s.chain != nullptr && (run_step % thin) == 0;
     const int64_t store_index = s.state->store_base + (run_step + thin - 1) / thin;   // stored steps before this one
     const int nhalf = s.nwalkers / 2;
-    const int64_t g = (int64_t)chain * nhalf + k;            // global walker slot: the Philox counter
+    const uint64_t sid = s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain;
+    const uint64_t g = sid * (uint64_t)nhalf + (uint64_t)k;  // walker slot of the chain's random stream: the Philox counter
     if (valid) {
     const int w = s.half * nhalf + k;                        // this walker, in the active half
     const int cbase = (1 - s.half) * nhalf;                  // complementary half
@@ -282,6 +287,7 @@ struct PersistArgs {
     int64_t nsteps;
     int32_t thin, store;
     double a;
+    const uint64_t* stream_ids;     // as StretchArgs::stream_ids
 };
 
 template <int NDIM, int MODE>
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_stretch_persist(const PersistArgs s)
             const int cbase = (1 - half) * nhalf;
             const uint64_t ctr = 2 * iteration + half;
             for (int k = threadIdx.x; k < nhalf; k += nt) {
-                const int64_t g = (int64_t)chain * nhalf + k;
+                const uint64_t g = (s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain) * (uint64_t)nhalf + (uint64_t)k;
                 const int w = half * nhalf + k;
                 uint32_t r[4];
                 philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r);
@@ -473,11 +479,14 @@ struct gf_sampler {
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
     int64_t steps_since_reset = 0;
+    uint64_t* d_stream_ids = nullptr;   // per-chain random stream ids (gf_sampler_set_stream_ids), else null
     StepState* d_state = nullptr;
     StepState h_state = {};
     // captured graph of GRAPH_STEPS steps (2 nodes per step + one tick), valid for the chain pointers it was built with
     hipGraphExec_t graph = nullptr;
     double* graph_chain = nullptr;
+    double* graph_lnp_chain = nullptr;
+    int64_t graph_cap = -1;
     int graph_has_chain = -1;
 };
 
@@ -567,6 +576,7 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
     if (s->d_commons) (void)hipFree(s->d_commons);
+    if (s->d_stream_ids) (void)hipFree(s->d_stream_ids);
     if (s->d_tbs) (void)hipFree((void*)s->d_tbs);
     if (s->d_ptabs) (void)hipFree((void*)s->d_ptabs);
     delete[] s->models;
@@ -622,6 +632,22 @@ int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, 
     cleanup();
     if (e != hipSuccess) { rc = sfail(e, "gf_sampler_create_multi"); gf_sampler_destroy(s); return rc; }
     *out = s;
+    return GF_OK;
+}
+
+// Random stream of every chain (default: the chain's index in this sampler).  ids [nchains]; call before the first run.
+int gf_sampler_set_stream_ids(gf_sampler* s, const uint64_t* ids)
+{
+    if (!s || !ids) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    GFS_HIP(hipStreamSynchronize(st));
+    if (!s->d_stream_ids) GFS_HIP(hipMalloc((void**)&s->d_stream_ids, sizeof(uint64_t) * (size_t)s->nchains));
+    GFS_HIP(hipMemcpyAsync(s->d_stream_ids, ids, sizeof(uint64_t) * (size_t)s->nchains, hipMemcpyHostToDevice, st));
+    GFS_HIP(hipStreamSynchronize(st));
+    if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }     // its kernel arguments froze the old pointer
     return GF_OK;
 }
 
@@ -701,6 +727,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             if (s->d_chain) (void)hipFree(s->d_chain);
             if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
             s->d_chain = nc; s->d_lnp_chain = nl; s->nstore_cap = cap;
+            // the captured graph froze the old buffers and their capacity stride in its kernel arguments
+            if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }
         }
     }
     // device-side step counters for this run
@@ -717,6 +745,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
     a.commons = s->models ? s->d_commons : nullptr; a.tbs = s->d_tbs; a.ptabs = s->d_ptabs;
     a.nbins_max = s->nbins_max;
+    a.stream_ids = s->d_stream_ids;
     a.lpw = lanes_per_walker(c->mode, (int64_t)s->nchains * (s->nwalkers / 2), s->nbins_max, s->cus);
     auto steps = [&](int count) -> hipError_t {       // `count` steps relative to the current base, then tick
         for (int i = 0; i < count; ++i) {
@@ -742,6 +771,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             pa.nwalkers = s->nwalkers; pa.pos = s->d_pos; pa.lnp = s->d_lnp; pa.naccept = s->d_naccept;
             pa.chain = store ? s->d_chain : nullptr; pa.lnp_chain = store ? s->d_lnp_chain : nullptr;
             pa.nstore_cap = s->nstore_cap; pa.seed = s->seed; pa.thin = thin; pa.store = store ? 1 : 0; pa.a = s->a;
+            pa.stream_ids = s->d_stream_ids;
             constexpr int64_t CHUNK = 1 << 16;                          // steps per launch: bounds a kernel's run time
             int64_t done_p = 0;
             while (done_p < nsteps) {
@@ -771,7 +801,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;          // diagnostics, read per run
     if (!no_graph && nsteps >= 2 * GRAPH_STEPS) {
         // launch-bound inner loop -> hipGraph: capture GRAPH_STEPS steps once, replay
-        if (!s->graph || s->graph_chain != a.chain || s->graph_has_chain != (store ? 1 : 0)) {
+        if (!s->graph || s->graph_chain != a.chain || s->graph_lnp_chain != a.lnp_chain || s->graph_cap != a.nstore_cap ||
+            s->graph_has_chain != (store ? 1 : 0)) {
             if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }
             hipGraph_t g = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -787,6 +818,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
                 s->graph = nullptr;
             } else {
                 s->graph_chain = a.chain;
+                s->graph_lnp_chain = a.lnp_chain;
+                s->graph_cap = a.nstore_cap;
                 s->graph_has_chain = store ? 1 : 0;
             }
         }
@@ -859,6 +892,29 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
     return GF_OK;
 }
 
+// The stored chain packed into caller-owned DEVICE buffers (the capacity padding of the sampler's own buffer removed):
+// d_chain [nchains][nstored][nwalkers][ndim], d_lnprob_chain [nchains][nstored][nwalkers]; either may be NULL.
+// Synchronous on return.  What a multi-GPU gather sends (gf_comm_allgather takes device pointers).
+int gf_sampler_get_chain_device(gf_sampler* s, double* d_chain, double* d_lnprob_chain)
+{
+    if (!s) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (s->nstored > 0) {
+        const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
+        if (d_chain)
+            GFS_HIP(hipMemcpy2DAsync(d_chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
+                                     hipMemcpyDeviceToDevice, st));
+        if (d_lnprob_chain)
+            GFS_HIP(hipMemcpy2DAsync(d_lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored,
+                                     s->nchains, hipMemcpyDeviceToDevice, st));
+    }
+    GFS_HIP(hipStreamSynchronize(st));
+    return GF_OK;
+}
+
 // mean [nchains][nstored][ndim]: the ensemble-averaged series whose integrated autocorrelation time the
 // reference prints (golemflavor/mcmc.py:45-51 sampler.acor); reduced on the device, only the means cross PCIe.
 int gf_sampler_walker_mean(gf_sampler* s, double* mean)
@@ -903,6 +959,33 @@ int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins
 // (scripts/mc_texture.py: the chain samples the priors, mc_texture.py:148-170, and every sample is then pushed
 // through flux_averaged_BSMu at the grid point's scale and source, mc_texture.py:216-221).  models == NULL:
 // the sampling models.  Each model must have the sampler's ndim and device.
+// Same with DEVICE destinations: d_fr [nchains][nstored][nwalkers][3], d_status [nchains][nstored][nwalkers] (NULL = skip);
+// synchronous on return.
+int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double* d_fr, int32_t* d_status)
+{
+    if (!s || !d_fr) return GF_ERR_INVALID_ARG;
+    const GfCommon* c0; const GfBsm* tb; const double* ptab; void* stream; int device0;
+    if (gf_model_internal(s->model, &c0, &tb, &ptab, &stream, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    for (int ch = 0; ch < s->nchains; ++ch) {
+        gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
+        const GfCommon* c; int device, cus, nbins;
+        if (gf_model_constants(mc, &c, &tb, &ptab, &device, &cus, &nbins) != GF_OK || c->ndim != s->ndim || device != device0)
+            return GF_ERR_INVALID_ARG;
+    }
+    GFS_HIP(hipSetDevice(device0));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per_chain = s->nstored * s->nwalkers;
+    int rc = GF_OK;
+    for (int ch = 0; ch < s->nchains && rc == GF_OK && per_chain > 0; ++ch) {
+        gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
+        const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
+        rc = gf_model_propagate_on(mc, stream, d_theta, GF_LAYOUT_AOS, per_chain, d_fr + (size_t)ch * per_chain * 3,
+                                   d_status ? d_status + (size_t)ch * per_chain : nullptr);
+    }
+    GFS_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
 int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
                                 uint64_t* counts)
 {

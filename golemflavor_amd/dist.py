@@ -7,14 +7,23 @@ data path has no collective, and only two exchanges exist -- a broadcast of the 
 descriptors at start and a gather of the chain blocks at the end.
 
 Backends
-  RcclBackend : RCCL over xGMI through the library's own C ABI (gf_comm_*); device-side
-                all-gather.  The 128-byte RCCL unique id is shipped out of band (a torch.distributed
-                store / gloo broadcast, or any user callable).
-  GlooBackend : torch.distributed on CPU tensors -- what the world_size-2 tests run on, and the
-                control plane (barrier, max-over-ranks) of bench.py.
-  LocalBackend: world size 1.
+  RcclBackend  : RCCL over xGMI through the library's own C ABI (gf_comm_*); device-side all-gather.  The
+                 128-byte RCCL unique id is shipped out of band by the control plane below.
+  SocketBackend: the control plane of bench.py and scan.py -- rendezvous, barrier, max-over-ranks, the unique id --
+                 over plain TCP sockets (standard library only; rank 0 listens, the others connect).  No PyTorch in
+                 the process: which librccl a process maps depends on what was imported first (torch bundles its
+                 own under the same soname), so the product's processes import nothing that links a ROCm runtime
+                 before libgolemhip.so.
+  GlooBackend  : torch.distributed on CPU tensors, for callers that already live inside a torch process group (and
+                 the world_size-2 gloo test).
+  LocalBackend : world size 1.
 """
 import ctypes as C
+import hashlib
+import os
+import socket
+import struct
+import time
 
 import numpy as np
 
@@ -41,11 +50,179 @@ class LocalBackend:
     def allgather(self, arr):
         return np.asarray(arr)[None, ...]
 
+    def allgather_bytes(self, payload):
+        return [bytes(payload)]
+
+    def allreduce_max(self, values):
+        return np.asarray(values, dtype=np.float64).reshape(-1)
+
     def barrier(self):
         pass
 
     def close(self):
         pass
+
+
+class SocketBackend:
+    """Control plane over TCP, standard library only.  Star topology: rank 0 listens on (addr, port) and relays.
+
+    addr / port default to MASTER_ADDR / GF_RDZV_PORT, else MASTER_PORT + 1 (torch.distributed.run keeps MASTER_PORT
+    itself for its own store); if that port is taken rank 0 walks up to 31 ports further and the clients follow,
+    recognising the right listener by a handshake that carries the job's token (TORCHELASTIC_RUN_ID by default).
+    Collectives: broadcast_bytes, allgather_bytes, allgather (numpy), barrier, allreduce_max."""
+
+    MAGIC = b"GFRDZV1\0"
+    PORT_SPAN = 32
+    OP_TIMEOUT = 1800.0       # a collective whose peer has died fails instead of hanging for ever
+
+    def __init__(self, rank, world, addr=None, port=None, token=None, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
+        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        if port is None:
+            port = int(os.environ.get("GF_RDZV_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29500")) + 1
+        tok = token if token is not None else os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "")
+        self._token = hashlib.sha256(("%s|%d" % (tok, self.world)).encode()).digest()
+        self._peers = {}          # rank 0: rank -> socket; others: {0: socket}
+        self._listener = None
+        deadline = time.monotonic() + float(timeout)
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            self._serve(int(port), deadline)
+        else:
+            self._connect(int(port), deadline)
+
+    # -- wire helpers ---------------------------------------------------------------------
+    @staticmethod
+    def _send(sock, payload):
+        sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+    @staticmethod
+    def _recv_exact(sock, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = sock.recv(min(n - len(buf), 1 << 20))
+            if not chunk:
+                raise ConnectionError("peer closed the rendezvous connection")
+            buf += chunk
+        return bytes(buf)
+
+    @classmethod
+    def _recv(cls, sock):
+        (n,) = struct.unpack("<Q", cls._recv_exact(sock, 8))
+        return cls._recv_exact(sock, n)
+
+    def _serve(self, port, deadline):
+        last = None
+        for p in range(port, port + self.PORT_SPAN):
+            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                ls.bind((self.addr, p))
+                ls.listen(self.world)
+                self._listener, self.port = ls, p
+                break
+            except OSError as exc:
+                last = exc
+                ls.close()
+        if self._listener is None:
+            raise OSError("rank 0 could not bind a rendezvous port in %d..%d: %s" % (port, port + self.PORT_SPAN - 1, last))
+        while len(self._peers) < self.world - 1:
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise TimeoutError("rendezvous: %d of %d ranks connected" % (len(self._peers) + 1, self.world))
+            self._listener.settimeout(left)
+            try:
+                conn, _ = self._listener.accept()
+            except socket.timeout:
+                continue
+            conn.settimeout(10.0)
+            try:
+                hello = self._recv_exact(conn, len(self.MAGIC) + 8 + 32)
+                magic, (w, r), tok = hello[:8], struct.unpack("<ii", hello[8:16]), hello[16:]
+                if magic != self.MAGIC or w != self.world or tok != self._token or not 0 < r < self.world or r in self._peers:
+                    conn.close()
+                    continue
+                conn.sendall(b"OK")
+            except (OSError, ConnectionError, struct.error):
+                conn.close()
+                continue
+            conn.settimeout(self.OP_TIMEOUT)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._peers[r] = conn
+
+    def _connect(self, port, deadline):
+        hello = self.MAGIC + struct.pack("<ii", self.world, self.rank) + self._token
+        while time.monotonic() < deadline:
+            for p in range(port, port + self.PORT_SPAN):
+                try:
+                    sk = socket.create_connection((self.addr, p), timeout=2.0)
+                except OSError:
+                    continue
+                try:
+                    sk.settimeout(5.0)
+                    sk.sendall(hello)
+                    if self._recv_exact(sk, 2) == b"OK":
+                        sk.settimeout(self.OP_TIMEOUT)
+                        sk.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._peers[0], self.port = sk, p
+                        return
+                except (OSError, ConnectionError):
+                    pass
+                sk.close()
+            time.sleep(0.05)
+        raise TimeoutError("rank %d could not reach the rendezvous at %s:%d.." % (self.rank, self.addr, port))
+
+    # -- collectives ------------------------------------------------------------------------
+    def allgather_bytes(self, payload):
+        """Every rank's payload, in rank order, on every rank."""
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv(self._peers[r]) for r in range(1, self.world)]
+            blob = b"".join(struct.pack("<Q", len(x)) + x for x in parts)
+            for r in range(1, self.world):
+                self._send(self._peers[r], blob)
+            return parts
+        self._send(self._peers[0], payload)
+        blob = self._recv(self._peers[0])
+        parts, o = [], 0
+        while o < len(blob):
+            (n,) = struct.unpack_from("<Q", blob, o)
+            parts.append(blob[o + 8:o + 8 + n])
+            o += 8 + n
+        return parts
+
+    def broadcast_bytes(self, buf, root=0):
+        if self.world == 1:
+            return bytes(buf)
+        return self.allgather_bytes(bytes(buf) if self.rank == root else b"")[root]
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        parts = self.allgather_bytes(a.tobytes())
+        return np.stack([np.frombuffer(x, dtype=a.dtype).reshape(a.shape) for x in parts])
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def allreduce_max(self, values):
+        v = np.asarray(values, dtype=np.float64).reshape(-1)
+        return self.allgather(v).max(axis=0)
+
+    def close(self):
+        for sk in self._peers.values():
+            try:
+                sk.close()
+            except OSError:
+                pass
+        self._peers = {}
+        if self._listener is not None:
+            self._listener.close()
+            self._listener = None
 
 
 class GlooBackend:
@@ -71,6 +248,14 @@ class GlooBackend:
         self._dist.all_gather(outs, t)
         return np.stack([o.numpy() for o in outs])
 
+    def allgather_bytes(self, payload):
+        outs = [None] * self.world
+        self._dist.all_gather_object(outs, bytes(payload))
+        return outs
+
+    def allreduce_max(self, values):
+        return self.allgather(np.asarray(values, dtype=np.float64).reshape(-1)).max(axis=0)
+
     def barrier(self):
         self._dist.barrier()
 
@@ -81,10 +266,10 @@ class GlooBackend:
 class RcclBackend:
     """RCCL over xGMI via gf_comm_* (one communicator per process, bound to `device`).
 
-    `exchange_id(id_bytes_or_None) -> id_bytes` ships rank 0's unique id to every rank; with
-    torch.distributed initialised (gloo) the default uses broadcast_object_list."""
+    `control`: the backend that ships rank 0's 128-byte unique id to the others (SocketBackend / GlooBackend), or a
+    callable `exchange_id(id_bytes_or_None) -> id_bytes`."""
 
-    def __init__(self, rank, world, device, exchange_id=None):
+    def __init__(self, rank, world, device, control=None):
         self._L = _lib.lib()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
         uid = None
@@ -92,20 +277,14 @@ class RcclBackend:
             buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
             _lib.check(self._L.gf_comm_unique_id(buf), "gf_comm_unique_id")
             uid = bytes(buf)
-        if exchange_id is None:
-            exchange_id = self._exchange_via_torch
-        uid = exchange_id(uid) if self.world > 1 else uid
+        if self.world > 1:
+            if control is None:
+                raise ValueError("RcclBackend needs a control backend to ship the unique id")
+            uid = control(uid) if callable(control) else control.broadcast_bytes(uid or b"", 0)
         idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(uid)
         h = C.c_void_p()
         _lib.check(self._L.gf_comm_create(idb, self.rank, self.world, self.device, C.byref(h)), "gf_comm_create")
         self._h = h
-
-    @staticmethod
-    def _exchange_via_torch(uid):
-        import torch.distributed as dist
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
 
     def broadcast_bytes(self, buf, root=0):
         raw = (C.c_uint8 * len(buf)).from_buffer_copy(bytes(buf))
@@ -135,34 +314,43 @@ class RcclBackend:
             self._h = None
 
 
-def open_rccl(rank, world, device, timeout=120.0):
-    """An RcclBackend whose bootstrap cannot hang the job: the communicator is created in a helper thread
-    with a bounded wait, and (world > 1) all ranks agree over torch.distributed whether everybody got one.
-    Returns (backend or None, error string or None)."""
+def rccl_library_info():
+    """'<ncclGetVersion code> <path of the librccl this process mapped>' (goes into the JSON lines)."""
+    buf = C.create_string_buffer(600)
+    _lib.check(_lib.lib().gf_comm_library_info(buf, 600), "gf_comm_library_info")
+    return buf.value.decode()
+
+
+def open_rccl(rank, world, device, control, timeout=120.0):
+    """An RcclBackend whose bootstrap cannot hang the job: the communicator is created in a helper thread with a
+    bounded wait, and (world > 1) all ranks agree over `control` whether everybody got one.
+    Returns (backend or None, error string or None, stuck) -- `stuck`: the helper thread never came back (the caller
+    must leave with os._exit after flushing its output: the thread would block interpreter shutdown)."""
     import threading
     box = {}
 
     def _setup():
         try:
-            box["b"] = RcclBackend(rank, world, device)
+            box["b"] = RcclBackend(rank, world, device, control=control)
         except Exception as exc:           # noqa: BLE001
             box["err"] = "%s: %s" % (type(exc).__name__, exc)
 
     th = threading.Thread(target=_setup, daemon=True)
     th.start()
     th.join(timeout=timeout)
-    err = "timeout: RCCL communicator setup did not finish" if th.is_alive() else box.get("err")
+    stuck = th.is_alive()
+    err = "timeout: RCCL communicator setup did not finish in %.0f s" % timeout if stuck else box.get("err")
     if world > 1:
-        import torch.distributed as tdist
-        errs = [None] * world
-        tdist.all_gather_object(errs, err)
-        err = next((e for e in errs if e is not None), None)
+        # every rank reports, the stuck one too (its helper thread is past the id exchange, inside ncclCommInitRank):
+        # nobody is left waiting in this exchange
+        errs = control.allgather_bytes((err or "").encode())
+        err = next((e.decode() for e in errs if e), None)
     if err is not None:
         b = box.get("b")
         if b is not None:
             b.close()
-        return None, err
-    return box["b"], None
+        return None, err, stuck
+    return box["b"], None, False
 
 
 def broadcast_descriptors(descs, backend, root=0):

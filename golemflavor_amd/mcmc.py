@@ -23,7 +23,6 @@ import sys
 
 import numpy as np
 
-from .enums import MCMCSeedType  # noqa: F401
 
 try:
     from tqdm import tqdm
@@ -80,7 +79,8 @@ class EnsembleSampler:
 
     # -- state -----------------------------------------------------------------------
     def reset(self):
-        self.iterations = 0
+        self.iterations = 0           # every iteration since the reset, stored or not (acceptance_fraction divides by it)
+        self._nstored = 0             # steps kept in the chain (every `thin`-th)
         self.naccepted = np.zeros(self.k)
         self._chain = np.empty((self.k, 0, self.dim))
         self._lnprob = np.empty((self.k, 0))
@@ -92,7 +92,7 @@ class EnsembleSampler:
     @property
     def chain(self):
         """(nwalkers, nsteps, ndim), as emcee-2 (mcmc.py:43 reshapes it to (-1, ndim))."""
-        return self._chain[:, :self.iterations]
+        return self._chain[:, :self._nstored]
 
     @property
     def flatchain(self):
@@ -100,7 +100,7 @@ class EnsembleSampler:
 
     @property
     def lnprobability(self):
-        return self._lnprob[:, :self.iterations]
+        return self._lnprob[:, :self._nstored]
 
     @property
     def acceptance_fraction(self):
@@ -152,13 +152,14 @@ class EnsembleSampler:
         lnprob = np.array(lnprob0, dtype=np.float64) if lnprob0 is not None else self._get_lnprob(p)
         if np.any(np.isnan(lnprob)):
             raise ValueError("The initial lnprob was NaN.")
+        thin = int(thin)
         if storechain:
-            n_new = iterations // thin
-            self._chain = np.concatenate((self._chain[:, :self.iterations],
+            n_new = (int(iterations) + thin - 1) // thin          # steps 0, thin, 2 thin, ... of this call
+            self._chain = np.concatenate((self._chain[:, :self._nstored],
                                           np.zeros((self.k, n_new, self.dim))), axis=1)
-            self._lnprob = np.concatenate((self._lnprob[:, :self.iterations],
+            self._lnprob = np.concatenate((self._lnprob[:, :self._nstored],
                                            np.zeros((self.k, n_new))), axis=1)
-        i0 = self.iterations
+        s0 = self._nstored
         first, second = slice(halfk), slice(halfk, self.k)
         for i in range(int(iterations)):
             for S0, S1 in ((first, second), (second, first)):
@@ -169,10 +170,11 @@ class EnsembleSampler:
                     p[idx] = q[acc]
                     self.naccepted[idx] += 1
             if storechain and i % thin == 0:
-                ind = i0 + i // thin
+                ind = s0 + i // thin
                 self._chain[:, ind, :] = p
                 self._lnprob[:, ind] = lnprob
-            self.iterations = i0 + i // thin + 1 if storechain else self.iterations + 1
+                self._nstored = ind + 1
+            self.iterations += 1
             yield p, lnprob, self.random_state
 
     def run_mcmc(self, pos0, N, **kwargs):
@@ -195,7 +197,7 @@ class DeviceEnsembleSampler:
     geometry), not from numpy's global state.
     """
 
-    def __init__(self, nwalkers, dim, lnpostfn, a=2.0, nchains=1, seed=0, threads=1):
+    def __init__(self, nwalkers, dim, lnpostfn, a=2.0, nchains=1, seed=0, threads=1, stream_ids=None):
         import ctypes as C
         from . import _lib
         multi = isinstance(lnpostfn, (list, tuple))
@@ -233,6 +235,14 @@ class DeviceEnsembleSampler:
         self._h = h
         self._have_state = False
         self.on_nonunitary = getattr(lnpostfn, "on_nonunitary", "raise")
+        if stream_ids is not None:
+            # one random stream per chain, named by the caller (a scan: the global grid index) instead of by the
+            # chain's position in this sampler: the chain of a grid point is then the same on any rank / in any stack
+            ids = np.ascontiguousarray(stream_ids, dtype=np.uint64)
+            if ids.shape != (self.nchains,):
+                raise ValueError("stream_ids must hold one id per chain (%d), got %s" % (self.nchains, ids.shape))
+            _lib.check(self._L.gf_sampler_set_stream_ids(self._h, ids.ctypes.data_as(C.POINTER(C.c_uint64))),
+                       "gf_sampler_set_stream_ids")
 
     # -- control ------------------------------------------------------------------------
     def _set_state(self, p0):
@@ -280,6 +290,8 @@ class DeviceEnsembleSampler:
         if p0 is not None:
             self._set_state(p0)
         chunk = int(chunk or max(1, iterations // 100))
+        thin = int(thin)
+        chunk = max(thin, (chunk // thin) * thin)       # every gf_sampler_run call starts on a stored step
         done = 0
         while done < iterations:
             m = min(chunk, iterations - done)
@@ -313,9 +325,10 @@ class DeviceEnsembleSampler:
 
     def _fetch(self, chain=False, lnprob=False, naccepted=False):
         """Only what is asked for crosses PCIe (the C entry point skips NULL arrays)."""
+        from .model import empty_for_download
         ns = int(self._L.gf_sampler_nstored(self._h))
-        c = np.empty((self.nchains, ns, self.k, self.dim)) if chain else None
-        lnp = np.empty((self.nchains, ns, self.k)) if lnprob else None
+        c = empty_for_download((self.nchains, ns, self.k, self.dim)) if chain else None
+        lnp = empty_for_download((self.nchains, ns, self.k)) if lnprob else None
         nacc = np.empty((self.nchains, self.k), dtype=np.uint32) if naccepted else None
         self._lib.check(self._L.gf_sampler_get_chain(
             self._h, c.ctypes.data_as(self._lib._dp) if chain else None, lnp.ctypes.data_as(self._lib._dp) if lnprob else None,
@@ -353,9 +366,10 @@ class DeviceEnsembleSampler:
         (mc_texture.py samples the priors and propagates with the grid point's texture model).
         step_major: leave 'fr' / 'status' in the device order (nsteps, nwalkers, ...), as `flat_steps`."""
         C = self._C
+        from .model import empty_for_download
         ns = int(self._L.gf_sampler_nstored(self._h))
-        fr = np.empty((self.nchains, ns, self.k, 3)) if want_fr else None
-        st = np.empty((self.nchains, ns, self.k), dtype=np.int32) if want_status else None
+        fr = empty_for_download((self.nchains, ns, self.k, 3)) if want_fr else None
+        st = empty_for_download((self.nchains, ns, self.k), dtype=np.int32) if want_status else None
         hist = np.zeros((self.nchains, nbins, nbins, nbins), dtype=np.uint64) if nbins else None
         handles = None
         if models is not None:
@@ -377,6 +391,24 @@ class DeviceEnsembleSampler:
         if nbins:
             out["hist"] = hist[0] if self.nchains == 1 else hist
         return out
+
+    @property
+    def nstored(self):
+        return int(self._L.gf_sampler_nstored(self._h))
+
+    def chain_to_device(self, d_chain):
+        """The stored chain, packed [nchains][nstored][nwalkers][ndim], into a device buffer of the caller's (what a
+        multi-GPU gather sends: `dist.RcclBackend.allgather_device`)."""
+        self._lib.check(self._L.gf_sampler_get_chain_device(self._h, d_chain, None), "gf_sampler_get_chain_device")
+
+    def postprocess_to_device(self, d_fr, d_status=None, models=None):
+        """`postprocess` with device destinations: d_fr [nchains][nstored][nwalkers][3], d_status optional."""
+        C = self._C
+        handles = None
+        if models is not None:
+            ms = [getattr(m, "model", m) for m in models]
+            handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
+        self._lib.check(self._L.gf_sampler_postprocess_device(self._h, handles, d_fr, d_status), "gf_sampler_postprocess_device")
 
     def flat_steps(self):
         """The stored samples in the order the device holds them, (nsteps*nwalkers, ndim) [leading chain axis
@@ -457,26 +489,6 @@ def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident
         print('WARNING : NEED TO RUN MORE SAMPLES')
 
     return samples
-
-
-def mcmc_argparse(parser):
-    """The MCMC command-line group of golemflavor/mcmc.py:56-85 (same flags and defaults)."""
-    def parse_bool(s):
-        return str(s).lower() in ("true", "t", "1", "yes", "y")
-
-    def seed_type(s):
-        return MCMCSeedType[str(s).upper()]
-
-    parser.add_argument('--run-mcmc', type=parse_bool, default='True', help='Run the MCMC')
-    parser.add_argument('--burnin', type=int, default=100, help='Amount to burnin')
-    parser.add_argument('--nwalkers', type=int, default=60, help='Number of walkers')
-    parser.add_argument('--nsteps', type=int, default=2000, help='Number of steps to run')
-    parser.add_argument('--mcmc-seed-type', default='uniform', type=seed_type, choices=MCMCSeedType,
-                        help='Type of distrbution to make the initial MCMC seed')
-    parser.add_argument('--plot-angles', type=parse_bool, default='False',
-                        help='Plot MCMC triangle in the angles space')
-    parser.add_argument('--plot-elements', type=parse_bool, default='False',
-                        help='Plot MCMC triangle in the mixing elements space')
 
 
 def solve_ratio(fr):

@@ -4,8 +4,10 @@ posterior of scripts/fr.py / sens.py's scale scan), sharded over one process per
 The reference runs one HTCondor job per grid point (submitter/mc_texture_dag.py:57-71,
 submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`), and all grid points
 of a rank are stacked into ONE device-resident sampler -- one ensemble per posterior, one launch per
-half-step for all of them; chains are gathered at the end (RCCL all-gather through
-`gf_comm_*`, or gloo / nothing for one rank).  No collective on the data path.
+half-step for all of them; chains are gathered at the end: RCCL all-gather (`gf_comm_allgather`)
+straight from the sampler's device chain buffer, one download on rank 0.  No collective on the data path.  The control
+plane (rendezvous, the RCCL id, barriers) is `dist.SocketBackend` -- no PyTorch in the process; any launcher that sets
+RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT works, torch.distributed.run included.
 
     python -m golemflavor_amd.scan --config C4 [--nwalkers 2048 --burnin 100 --nsteps 200]
     python -m torch.distributed.run --nproc-per-node 8 ... -m golemflavor_amd.scan --config C5
@@ -52,16 +54,25 @@ class _TexturePoint:
                              bestfit_fr=(1 / 3,) * 3, smearing=0.02)
         self.post_model = Model(desc, device=device)           # the chain is propagated with this one, on the device
 
+    @staticmethod
+    def assemble(samples, frs, status):
+        frs = np.array(frs)
+        frs[status != 0] = np.nan                                              # the reference would have raised there
+        out = np.empty((samples.shape[0], 9))
+        out[:, :3] = frs
+        out[:, 3:] = samples
+        return out
+
+    def close(self):
+        self.f.close()
+        self.post_model.close()
+
     def collect(self, samples, frs=None, status=None):
         """samples: this point's flat chain (nwalkers*nsteps, 6); frs/status: its device post-processing"""
         if frs is None:
             frs, status = self.post_model.propagate(samples)
-        frs[status != 0] = np.nan                                              # the reference would have raised there
-        self.f.close()
-        self.post_model.close()
-        out = np.empty((samples.shape[0], 9))
-        out[:, :3] = frs
-        out[:, 3:] = samples
+        out = self.assemble(samples, frs, status)
+        self.close()
         return out
 
 
@@ -96,18 +107,30 @@ class _SensPoint:
 
     post_model = None
 
-    def collect(self, samples, frs=None, status=None):
+    @staticmethod
+    def assemble(samples, frs, status):
+        return np.array(samples)
+
+    def close(self):
         self.f.close()
+
+    def collect(self, samples, frs=None, status=None):
+        self.close()
         return samples
 
 
 PHASES = {}          # wall-clock seconds of the last run_points call, by phase (reported by main)
 
 
-def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25):
+def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gather=None):
     """All of this rank's grid points advance together.  stacked (default): one sampler, one ensemble per
-    grid point's posterior, every half-step of every chain in one launch.  Otherwise one sampler per point,
-    each on its own stream (`run_async`), so that the small launches overlap on the GPU."""
+    grid point's posterior, every half-step of every chain in one launch; chain g draws from random stream g (its
+    GLOBAL grid index), so that a grid point's chain does not depend on the number of ranks.  Otherwise one sampler per
+    point, each on its own stream (`run_async`), so that the small launches overlap on the GPU.
+
+    gather: None -> {grid index: collected array} of this rank's points (host);
+            a `DeviceGather` -> every grid point's array, in grid order, on rank 0 (None elsewhere): the chain blocks
+            go from the sampler's device buffer through RCCL and cross PCIe once."""
     t0 = time.perf_counter()
     jobs = {g: make(points[g], g) for g in indices}
     if not jobs:
@@ -118,13 +141,21 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25):
     PHASES["setup"] = time.perf_counter() - t0
     if stacked:
         t0 = time.perf_counter()
-        sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed)
+        sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed,
+                                                   stream_ids=order)
         sampler.on_nonunitary = "-inf"
         sampler.run_mcmc(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
         sampler.reset()
         sampler.run_mcmc(None, nsteps)
         PHASES["sampling"] = time.perf_counter() - t0
         t0 = time.perf_counter()
+        if gather is not None:
+            out = gather.run(sampler, jobs, order, len(points))
+            sampler.close()
+            for j in jobs.values():
+                j.close()
+            PHASES["gather"] = time.perf_counter() - t0
+            return out
         flat = sampler.flat_steps()                               # (npoints, nsteps*nwalkers, ndim), device order
         frs = sts = None
         if first.post_model is not None:                          # mc_texture.py:216-221 on the device
@@ -156,6 +187,50 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25):
         sm.close()
         out[g] = jobs[g].collect(flat)
     return out
+
+
+class DeviceGather:
+    """The chain gather of a stacked scan on the device: every rank packs its chains (and, for mc_texture, their
+    post-processed compositions) into one device block of `slots` grid points, RCCL all-gathers the blocks over xGMI
+    (`rccl`: dist.RcclBackend; None with one rank), and rank 0 downloads the result once, into prefaulted memory."""
+
+    def __init__(self, rccl, rank, world, model_for_buffers):
+        self.rccl, self.rank, self.world, self.m = rccl, rank, world, model_for_buffers
+
+    def _exchange(self, d_send, nbytes, shape, dtype):
+        if self.rccl is None:
+            return d_send.download(shape[1:], dtype=dtype)[None] if self.rank == 0 else None
+        d_recv = self.m.alloc(nbytes * self.world)
+        self.rccl.allgather_device(d_send.ptr, d_recv.ptr, nbytes)
+        out = d_recv.download(shape, dtype=dtype) if self.rank == 0 else None
+        d_recv.free()
+        return out
+
+    def run(self, sampler, jobs, order, n_points):
+        slots = gdist.slots_per_rank(n_points, self.world)
+        first = jobs[order[0]]
+        per = sampler.nstored * first.nwalkers                    # samples per grid point
+        ndim = first.ndim
+        blk = slots * per * ndim * 8
+        d_chain = self.m.alloc(blk)                               # ranks with fewer points leave the tail unused
+        sampler.chain_to_device(d_chain.ptr)
+        chains = self._exchange(d_chain, blk, (self.world, slots, per, ndim), np.float64)
+        d_chain.free()
+        frs = sts = None
+        if first.post_model is not None:                          # mc_texture.py:216-221 on the device, gathered too
+            d_fr, d_st = self.m.alloc(slots * per * 3 * 8), self.m.alloc(slots * per * 4)
+            sampler.postprocess_to_device(d_fr.ptr, d_st.ptr, models=[jobs[g].post_model for g in order])
+            frs = self._exchange(d_fr, slots * per * 3 * 8, (self.world, slots, per, 3), np.float64)
+            sts = self._exchange(d_st, slots * per * 4, (self.world, slots, per), np.int32)
+            d_fr.free()
+            d_st.free()
+        if self.rank != 0:
+            return None
+        out = []
+        for g in range(n_points):
+            r, sl = g % self.world, g // self.world
+            out.append(first.assemble(chains[r, sl], None if frs is None else frs[r, sl], None if sts is None else sts[r, sl]))
+        return out
 
 
 def point_filename(config, point, a):
@@ -190,12 +265,7 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = int(os.environ.get("GF_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    backend = gdist.LocalBackend()
-    if world > 1:
-        import torch.distributed as tdist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        backend = gdist.GlooBackend()
+    control = gdist.SocketBackend(rank, world) if world > 1 else gdist.LocalBackend()
 
     t0 = time.perf_counter()
     if a.config == "C4":
@@ -209,41 +279,50 @@ def main(argv=None):
         nw = a.nwalkers or 512
         make = lambda p, g: _SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
         evals_per_point = nw * (a.burnin + a.nsteps)
-    mine = gdist.shard(len(pts), backend.rank, backend.world)
-    local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=not a.no_stack)
-    if a.datadir:
-        # the reference's jobs each save their own chain to the shared filesystem; so does every rank here
-        for g in mine:
-            mcmc_utils.save_chains(local[g], os.path.join(a.datadir, point_filename(a.config, pts[g], a)))
-    t1 = time.perf_counter()
-    # chain blocks travel over RCCL / xGMI (device all-gather through the library's own communicator); gloo is
-    # the fallback when the communicator cannot be set up, and the control plane either way
-    rccl, rccl_err, allgather = None, None, None
+    mine = gdist.shard(len(pts), rank, world)
+    # chain blocks travel over RCCL / xGMI, device buffer to device buffer; if the communicator cannot be set up the
+    # blocks go through the host control plane instead and the failure is reported
+    rccl, rccl_err, stuck = None, None, False
     if world > 1 or os.environ.get("GF_SCAN_RCCL"):
-        rccl, rccl_err = gdist.open_rccl(rank, world, device, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
-    if rccl is not None:
+        rccl, rccl_err, stuck = gdist.open_rccl(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+    stacked = not a.no_stack
+    device_gather = stacked and not a.datadir and (rccl is not None or world == 1) and len(pts) >= world
+    if device_gather:
         stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
-        allgather = lambda arr: rccl.allgather(arr, stage)  # noqa: E731
-    chains = gdist.gather_chains(local, len(pts), backend, allgather=allgather)
-    if rccl is not None:
+        chains = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=True, gather=DeviceGather(rccl, rank, world, stage))
         stage.close()
+    else:
+        local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=stacked)
+        if a.datadir:
+            # the reference's jobs each save their own chain to the shared filesystem; so does every rank here
+            for g in mine:
+                mcmc_utils.save_chains(local[g], os.path.join(a.datadir, point_filename(a.config, pts[g], a)))
+        t1 = time.perf_counter()
+        chains = gdist.gather_chains(local, len(pts), control)
+        PHASES["gather"] = time.perf_counter() - t1
+    if rccl is not None:
         rccl.close()
-    PHASES["gather"] = time.perf_counter() - t1
     dt = time.perf_counter() - t0
     if rank == 0:
         if a.outfile:
             mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
-                          "nsteps": a.nsteps, "stacked": not a.no_stack,
-                          "gather": "rccl" if rccl is not None else ("gloo" if world > 1 else "local"), "rccl_error": rccl_err,
+                          "nsteps": a.nsteps, "stacked": stacked,
+                          "gather": ("rccl device all-gather" if rccl is not None else "device -> host") if device_gather
+                          else ("socket control plane" if world > 1 else "local"),
+                          "rccl_error": rccl_err, "librccl": gdist.rccl_library_info(),
                           "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,
                           "phases": {k: round(v, 4) for k, v in PHASES.items()},
                           "evals_per_s": len(pts) * evals_per_point / dt,
-                          "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}))
-    if world > 1:
-        import torch.distributed as tdist
-        tdist.barrier()
-        tdist.destroy_process_group()
+                          "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}), flush=True)
+    control.barrier()
+    control.close()
+    if rccl_err is not None:
+        # the run is complete (host gather) but the RCCL path is broken: say so with the exit status too
+        import sys
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3) if stuck else sys.exit(3)
 
 
 if __name__ == "__main__":

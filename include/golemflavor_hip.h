@@ -173,6 +173,10 @@ int gf_haar_draw_device(gf_model* m, uint64_t seed, int64_t first_draw, int64_t 
 int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int nbins, uint64_t* d_counts);
 int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uint64_t* counts);
 int gf_model_sync(gf_model* m);
+/* Touch the pages of a freshly allocated host buffer (content clobbered) from several threads, so that a following
+ * large device-to-host copy (gf_sampler_get_chain, gf_memcpy_d2h: sampler.chain of golemflavor/mcmc.py:43) runs at
+ * PCIe speed instead of page-fault speed. */
+int gf_host_prepare(void* buf, size_t bytes);
 
 /* HIP events on the model's stream (what bench.py times the kernel with) */
 int gf_event_create(void** ev);
@@ -194,6 +198,10 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
  * grid point; here all of a GPU's grid points advance in one launch per half-step).  Chain ch samples the
  * posterior of models[ch]; the models share device, ndim and mode and must outlive the sampler. */
 int gf_sampler_create_multi(gf_model* const* models, int nchains, int nwalkers, uint64_t seed, double a, gf_sampler** out);
+/* Random stream of each chain, ids [nchains] (default: the chain's index in this sampler).  A grid scan passes the
+ * global grid index, so that a grid point's chain is the same whichever rank runs it and whatever else shares its
+ * sampler (the reference's jobs are seeded per job, scripts/mc_texture.py:137-138).  Before the first run. */
+int gf_sampler_set_stream_ids(gf_sampler* s, const uint64_t* ids);
 void gf_sampler_destroy(gf_sampler* s);
 /* p0 [nchains][nwalkers][ndim]; evaluates its lnprob on the device (mcmc.py:34 sampler.sample(p0, ...)) */
 int gf_sampler_set_state(gf_sampler* s, const double* pos);
@@ -208,6 +216,8 @@ int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob);
 /* chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
  * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on; NULL = skip */
 int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary);
+/* the stored chain packed into caller-owned DEVICE buffers (what gf_comm_allgather sends); NULL = skip; synchronous */
+int gf_sampler_get_chain_device(gf_sampler* s, double* d_chain, double* d_lnprob_chain);
 /* mean [nchains][nstored][ndim]: ensemble mean of every stored step, the series behind sampler.acor
  * (golemflavor/mcmc.py:45-51), reduced on the device */
 int gf_sampler_walker_mean(gf_sampler* s, double* mean);
@@ -220,6 +230,9 @@ int gf_sampler_postprocess(gf_sampler* s, double* fr, int32_t* status, int nbins
  * priors (:148-170) and pushes every sample through flux_averaged_BSMu of the grid point (:216-221) */
 int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
                                 uint64_t* counts);
+
+/* same with DEVICE destinations d_fr [nchains][nstored][nwalkers][3], d_status (NULL = skip); synchronous */
+int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double* d_fr, int32_t* d_status);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only
@@ -234,6 +247,8 @@ void gf_comm_destroy(gf_comm* c);
 int gf_comm_broadcast(gf_comm* c, void* host_buf, size_t bytes, int root);            /* host in/out   */
 int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank); /* device  */
 int gf_comm_barrier(gf_comm* c);
+const char* gf_comm_last_error(void);                 /* thread-local text of the last failing gf_comm_* call */
+int gf_comm_library_info(char* buf, size_t buflen);   /* "<ncclGetVersion code> <path of the loaded librccl>" */
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,63 @@ def test_world_size_2_gloo(tmp_path):
         s = mcmc_utils.EnsembleSampler(8, 2, F(), seed=100 + g)
         s.run_mcmc(np.random.default_rng(g).normal(mu, sig, size=(8, 2)), 30)
         assert np.array_equal(a[g], s.flatchain)
+
+
+_SOCKET_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from golemflavor_amd import dist as gdist
+rank, world, port = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+b = gdist.SocketBackend(rank, world, addr="127.0.0.1", port=port, token="test-job", timeout=60)
+out = {"rank": rank, "port": b.port}
+out["bcast"] = b.broadcast_bytes(b"physics constants" if rank == 0 else b"", 0).decode()
+out["bcast_from_last"] = b.broadcast_bytes(b"x%d" % rank, world - 1).decode()
+out["gather"] = b.allgather(np.arange(3, dtype=np.float64) + 10 * rank).tolist()
+out["max"] = b.allreduce_max([float(rank), 5.0 - rank]).tolist()
+b.barrier()
+# the descriptor broadcast and the chain gather of the scan, on this control plane
+from golemflavor_amd._lib import GfModelDesc
+d = GfModelDesc(); d.ndim = 7 if rank == 0 else 0; d.smearing = 0.02 if rank == 0 else 0.0
+descs = gdist.broadcast_descriptors([d, d] if rank == 0 else [], b)
+out["descs"] = [(x.ndim, x.smearing) for x in descs]
+n = 5
+local = {g: np.full((2, 3), float(g)) for g in gdist.shard(n, rank, world)}
+chains = gdist.gather_chains(local, n, b)
+out["chains"] = [float(c[0, 0]) for c in chains]
+b.close()
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_socket_rendezvous_world_size_n(world, tmp_path):
+    """The stdlib control plane of bench.py / scan.py (no torch in the process): `world` spawned processes meet on a TCP
+    port, broadcast, all-gather, barrier, max-reduce, and run the scan's descriptor broadcast and chain gather on it.
+    The port handed over is deliberately occupied: rank 0 moves to the next free one and the others find it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_SOCKET_CHILD)
+    blocker = socket.socket()
+    blocker.bind(("127.0.0.1", 0))
+    blocker.listen(1)
+    port = blocker.getsockname()[1]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=120)
+        assert p.returncode == 0, se
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    blocker.close()
+    for r, o in enumerate(outs):
+        assert o["rank"] == r and o["port"] != port and o["port"] == outs[0]["port"]
+        assert o["bcast"] == "physics constants" and o["bcast_from_last"] == "x%d" % (world - 1)
+        assert o["gather"] == [[10.0 * q + k for k in range(3)] for q in range(world)]
+        assert o["max"] == [world - 1.0, 5.0]
+        assert o["descs"] == [[7, 0.02], [7, 0.02]]
+        assert o["chains"] == [0.0, 1.0, 2.0, 3.0, 4.0]

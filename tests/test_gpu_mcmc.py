@@ -98,7 +98,8 @@ def test_grid_scans_c4_c5_smoke(capsys):
     assert out["chains_shape"] == [3, 32 * 15, 9] and out["finite_fraction"] > 0.9
     scan.main(["--config", "C5", "--points", "2", "--nwalkers", "32", "--burnin", "5", "--nsteps", "10"])
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0 and out["gather"] == "local"
+    assert out["chains_shape"] == [2, 32 * 10, 12] and out["finite_fraction"] == 1.0 and out["gather"] == "device -> host"
+    assert "librccl" in out["librccl"]                                 # the RCCL this process mapped is on record
 
 
 def test_grid_scan_one_sampler_per_point_path(capsys):
@@ -138,9 +139,35 @@ def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
     monkeypatch.setenv("GF_SCAN_RCCL", "1")
     scan.main(args + ["--outfile", str(tmp_path / "rccl")])
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert out["gather"] == "rccl" and out["rccl_error"] is None
+    assert out["gather"] == "rccl device all-gather" and out["rccl_error"] is None
     a, b = np.load(str(tmp_path / "local.npy")), np.load(str(tmp_path / "rccl.npy"))
     assert a.shape == (3, 32 * 15, 9) and np.array_equal(a, b, equal_nan=True)
+
+
+def test_grid_point_chain_does_not_depend_on_the_sharding():
+    """Every chain of a stacked scan draws from the random stream of its GLOBAL grid index (gf_sampler_set_stream_ids):
+    grid points 1 and 3 give bitwise the same chains whether their rank holds all four points (world 1) or just
+    those two (rank 1 of world 2), and so does the one-sampler-per-point path's keying by grid index."""
+    from golemflavor_amd import scan
+    pts = scan.sens_grid(n_scales=2, n_sources=1)[:4]
+    make = lambda p, g: scan._SensPoint(p, g, nwalkers=32, device=0)   # noqa: E731
+    full = scan.run_points(pts, [0, 1, 2, 3], make, 5, 12)
+    half = scan.run_points(pts, gdist.shard(4, 1, 2), make, 5, 12)
+    assert sorted(half) == [1, 3]
+    for g in (1, 3):
+        assert np.array_equal(full[g], half[g])
+    assert not np.array_equal(full[0][:, :4], full[1][:, :4])          # distinct streams per grid point
+
+
+def test_rccl_error_text_reaches_python():
+    """GF_ERR_COMM carries the failing RCCL call's text (gf_comm_last_error is bound)."""
+    import ctypes as C
+    L = _lib.lib()
+    h = C.c_void_p()
+    bad = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
+    assert L.gf_comm_create(bad, 3, 2, 0, C.byref(h)) == _lib.GF_ERR_INVALID_ARG       # rank outside the world
+    info = gdist.rccl_library_info()
+    assert "librccl" in info and int(info.split()[0]) > 20000
 
 
 def test_integration_md_stub_is_executable(golden, oracle):

@@ -427,8 +427,9 @@ def test_chain_postprocessing_on_device(golden, oracle):
     m.close()
 
 
-def test_multinest_style_cube_adapter(golden):
-    """mn.py:26-45: unit cube -> scanned params, other columns fixed, batched."""
+def test_multinest_style_cube_adapter(golden, oracle):
+    """mn.py:26-45: unit cube -> scanned params, other columns fixed, batched.  Pinned on the oracle: theta is mapped
+    on the host exactly as mn.py:33-39 writes it and handed to the oracle's llh.ln_prob."""
     asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
     args = bsm_args(6, Texture.OET, (0., 1., 0.))
     f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.05, on_nonunitary="-inf")
@@ -443,6 +444,15 @@ def test_multinest_style_cube_adapter(golden):
     theta = np.column_stack([(hi - lo) * cube + lo, np.full(50, -50.0)])
     assert g.on_device                                             # the map ran in gf_lnprob_cube_batch ...
     assert np.array_equal(out, f(theta))                           # ... and is bitwise mn.py:36's expression
+    # ... and the values are the reference's: the oracle on the host-mapped theta (mn.py:33-39 -> llh.ln_prob)
+    pr = mn_ps.ranges
+    theta_ref = np.array([[(pr[i][1] - pr[i][0]) * c[i] + pr[i][0] for i in range(11)] + [-50.0] for c in cube])
+    from golemflavor_amd import fr as fr_host
+    om = oracle.make_model(ps, "BSM_GAUSS", texture="OET", dimension=6, binning=args.binning, source_ratio=(0., 1., 0.),
+                           bestfit_fr=fr_host.angles_to_fr((0.4444444444444444, 0.0)), smearing=0.05)
+    ref, ref_st = oracle.lnprob_batch(om, theta_ref, want_status=True)
+    assert np.all(ref_st == 0) and np.isfinite(ref).all()
+    assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
     assert g(list(cube[3]), 11, 11) == out[3]
     with pytest.raises(AssertionError):
         g(cube[0], 10, 10)

@@ -287,3 +287,24 @@ def test_header_is_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"),
                         "-c", os.path.join(root, "tests", "cabi", "smoke.c"), "-o", obj], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_host_sampler_thinning_counts_every_iteration():
+    """emcee-2 semantics (what golemflavor/mcmc.py:45 prints): `iterations` counts every step, the chain keeps every
+    `thin`-th one, acceptance_fraction = naccepted / iterations -- also across several sample() calls."""
+    from golemflavor_amd import mcmc
+
+    def lnp(x):
+        return -0.5 * float(np.sum(np.asarray(x) ** 2))
+
+    s = mcmc.EnsembleSampler(8, 2, lnp, seed=3)
+    p0 = np.random.default_rng(0).normal(size=(8, 2))
+    pos = s.run_mcmc(p0, 30, thin=3)[0]
+    assert s.iterations == 30 and s.chain.shape == (8, 10, 2) and s.lnprobability.shape == (8, 10)
+    s.run_mcmc(pos, 10, thin=3)                          # stores steps 0, 3, 6, 9 of this call
+    assert s.iterations == 40 and s.chain.shape == (8, 14, 2)
+    assert np.all(s.acceptance_fraction <= 1.0) and np.all(s.naccepted <= 40)
+    unthinned = mcmc.EnsembleSampler(8, 2, lnp, seed=3)
+    unthinned.run_mcmc(p0, 30)
+    assert np.array_equal(unthinned.chain[:, ::3], s.chain[:, :10])       # same random stream, every third step kept
+    assert np.array_equal(unthinned.naccepted / 30, unthinned.acceptance_fraction)
