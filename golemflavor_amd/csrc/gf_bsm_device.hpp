@@ -17,11 +17,12 @@ constexpr int TEX_NONE = 4;
 //  1. the weight `a` of the SM term in the trace-normalised Hamiltonian H' = a S' + t N'.  The amplification grows like
 //     1/a (the SM term is what lifts the zero eigenvalue of the NP term): over 30 000 pairs of every operator dimension
 //     and texture incl. random NP angles the 80-bit residual never exceeds 1.3e-19 / a (tools/uni_weight_bound.py,
-//     profiles/r02/uni_weight_bound.txt).  a >= uni_a_ok (1e-10; residual < 2e-9): unitary, nothing is evaluated --
+//     profiles/r02/uni_weight_bound.txt).  a >= uni_a_ok (2e-11; residual < 7e-9): unitary, nothing is evaluated --
 //     the whole low-scale bulk of a posterior costs nothing extra;
 //  2. else the same eigenvector form in fp64, whose residual `rr` is the noise 2^11 times louder: an ESTIMATE.  Where
-//     fp64 still resolves the SM term (a >= uni_a_lin = 1e-13) it is good to about two decades either way, below that
-//     it can overestimate without bound.  rr below uni_lo: unitary; rr above uni_hi in the resolved regime: not unitary;
+//     fp64 still resolves the SM term (a >= uni_a_lin = 1e-16) it is within [-2.2, +2.1] decades of the 80-bit value
+//     (180 000 walkers, tools/uni_estimate_spread.py); below that it errs by up to four decades either way.  rr below
+//     uni_lo (uni_lo_nl in the unresolved regime): unitary; rr above uni_hi in the resolved regime: not unitary;
 //  3. everything else is queued for the x87-faithful evaluation of gf_unitarity.hip, which decides.
 // The device sampler, which needs the verdict inside the kernel, stops at tier 2 (rr against the scaled threshold).
 constexpr double UNI_EST_SCALE = 2048.0;
@@ -244,8 +245,9 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
         double rr = 2.0 * off;                                         // |sum|XX^+| - 3| with the trace at 3
         if (rr != rr) rr = gf_inf();                                   // NaN fails the reference's test too
         acc.est_max = fmax(acc.est_max, rr);
-        if (a >= tb->uni_a_lin) acc.clear_max = fmax(acc.clear_max, rr);
-        if (rr >= tb->uni_lo) acc.amb |= 1ull << kbin;                 // this bin's verdict is not safe from the estimate
+        const bool resolved = a >= tb->uni_a_lin;                      // fp64 still sees the SM term
+        if (resolved) acc.clear_max = fmax(acc.clear_max, rr);
+        if (rr >= (resolved ? tb->uni_lo : tb->uni_lo_nl)) acc.amb |= 1ull << kbin;   // not safe from the estimate
     }
 }
 

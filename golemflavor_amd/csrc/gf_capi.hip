@@ -497,24 +497,26 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
                     b.t2_re[3 * i + j] = (double)t2.real(); b.t2_im[3 * i + j] = (double)t2.imag();
                 }
         }
-        // Unitarity tiers (gf_bsm_device.hpp).  Tier 1: SM weight a >= 1e-10 -> unitary (80-bit residual <= 1.3e-19 / a
-        // over 30 000 pairs, tools/uni_weight_bound.py).  Tier 2, the fp64 estimate: measured against the 80-bit residual
-        // over the transition zone of all 18 (dimension, texture) pairs (tools/uni_estimate_spread.py), log10(estimate /
-        // residual) spans [-2.3, +1.9] while fp64 resolves the SM term (a >= 1e-12) and [-4.0, +7.6] below -- there the
-        // estimate may only acquit (with margin), never condemn.  (GF_UNI_BAND_DECADES: symmetric override of the
-        // estimate's band, diagnostics; 0 = estimate only.)
+        // Unitarity tiers (gf_bsm_device.hpp).  Tier 1: SM weight a >= 2e-11 -> unitary (80-bit residual <= 1.3e-19 / a
+        // over 30 000 pairs, tools/uni_weight_bound.py: five-fold margin; no walker with a > 1.1e-13 fails).  Tier 2, the
+        // fp64 estimate, measured against the 80-bit residual on 180 000 walkers of all (dimension, texture) pairs binned by
+        // a (tools/uni_estimate_spread.py, profiles/r02/uni_estimate_spread.txt): log10(estimate / residual) lies in
+        // [-2.2, +2.1] wherever fp64 resolves the SM term (a >= 1e-16) and in [-4.0, +4.5] below -- there the estimate
+        // acquits only with that margin and never condemns.  (GF_UNI_BAND_DECADES: symmetric override of the resolved
+        // regime's band, diagnostics; 0 = estimate only.)
         {
-            double lo_dec = 4.5, hi_dec = 2.5;
-            b.uni_a_ok = 1e-10;
-            b.uni_a_lin = 1e-12;
+            double lo_dec = 2.7, hi_dec = 2.6, lo_nl_dec = 4.6;
+            b.uni_a_ok = 2e-11;
+            b.uni_a_lin = 1e-16;
             if (const char* e = std::getenv("GF_UNI_BAND_DECADES")) {
                 const double v = std::atof(e);
-                if (v >= 0.0 && v <= 12.0) { lo_dec = hi_dec = v; if (v == 0.0) b.uni_a_lin = 0.0; }
+                if (v >= 0.0 && v <= 12.0) { lo_dec = hi_dec = lo_nl_dec = v; if (v == 0.0) b.uni_a_lin = 0.0; }
             }
             b.uni_lo = 1e-7 * 2048.0 * std::pow(10.0, -lo_dec);
             b.uni_hi = 1e-7 * 2048.0 * std::pow(10.0, hi_dec);
+            b.uni_lo_nl = 1e-7 * 2048.0 * std::pow(10.0, -lo_nl_dec);
             if (std::getenv("GF_UNI_NO_WEIGHT_GATE")) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
-            if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the fp64 estimate
+            if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = b.uni_lo_nl = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the estimate
         }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order
         {

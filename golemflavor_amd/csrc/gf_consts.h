@@ -66,7 +66,8 @@ struct GfBsm {
     // which the fp64 estimate may condemn a bin; the estimate (2^11 x the x87 residual) below which a bin is unitary and
     // at or above which it is not
     double uni_a_ok, uni_a_lin;
-    double uni_lo, uni_hi;
+    double uni_lo, uni_hi;          // a >= uni_a_lin
+    double uni_lo_nl;               // a <  uni_a_lin: the estimate acquits only far below the threshold and never condemns
 };
 
 // Work queue of the unitarity arbitration: (walker, energy bin) pairs whose fp64 estimate of the reference's
