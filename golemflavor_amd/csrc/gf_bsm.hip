@@ -44,13 +44,26 @@ using namespace gfdev;
 // LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
 // SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
 // walkers per tile.  Results are bitwise those of LPW = 1.
-template <int NDIM, bool WITH_LLH, bool CHECK_UNI, int LPW>
-__global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
+// Push the undecided bins of walker `i` (bit k of `amb` = energy bin k) onto the arbitration queue
+__device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t i, unsigned long long amb)
+{
+    const unsigned int cnt = (unsigned int)__popcll(amb);
+    const unsigned int at = atomicAdd(&uq->count, cnt);
+    unsigned int j = 0;
+    for (unsigned long long mrest = amb; mrest != 0; mrest &= mrest - 1, ++j)
+        if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)i * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
+}
+
+// UNI_MODE (gf_bsm_device.hpp): UNI_NONE no status; UNI_INLINE tiers 1-2 inside the evaluation (small batches);
+// UNI_DEFER the evaluation only notes the walkers tier 1 does not clear (`wq`) and k_bsm_tier2 runs tier 2 on those.
+template <int NDIM, bool WITH_LLH, int UNI_MODE, int LPW>
+__global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, int64_t qbase)
+                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
 {
+    constexpr bool CHECK_UNI = UNI_MODE == UNI_INLINE;
     // the constants by pointer (the model's device block), not by value: as a 848-B kernel argument the compiler loads
     // every field up front and spills ~100 scalar registers to VGPR lanes around the tile loop (356 v_readlane /
     // v_writelane per tile in the by-value build)
@@ -92,22 +105,19 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
             double val = -gf_inf();
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
-                UniAcc acc = {0.0, 0.0, 0ull};
-                flux_average<CHECK_UNI, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
-                const unsigned long long amb = acc.amb;
+                UniAcc acc = {0.0, 0.0, 0ull, 2.0};
+                flux_average<UNI_MODE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
                 st = ST_OK;
                 if (CHECK_UNI) {
                     if (tb->uni_lo < 0.0) fr[0] = acc.est_max * (1.0 / UNI_EST_SCALE);  // diagnostics (GF_UNI_DUMP): the estimate itself
                     if (!(acc.clear_max < tb->uni_hi)) st = ST_NON_UNITARY;
-                    else if (amb != 0 && sub == 0 && uq) {
-                        // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
-                        // walker counts as unitary.  Walker indices in the queue are those of the whole batch.
-                        const unsigned int cnt = (unsigned int)__popcll(amb);
-                        const unsigned int at = atomicAdd(&uq->count, cnt);
-                        unsigned int j = 0;
-                        for (unsigned long long mrest = amb; mrest != 0; mrest &= mrest - 1, ++j)
-                            if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)(qbase + i) * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
-                    }
+                    // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
+                    // walker counts as unitary
+                    else if (acc.amb != 0 && sub == 0 && uq) queue_pairs(uq, i, acc.amb);
+                }
+                if (UNI_MODE == UNI_DEFER && acc.a_min < tb->uni_a_ok) {
+                    const unsigned int at = atomicAdd(&wq->count, 1u);          // tier 1 does not clear this walker
+                    if (at < wq->cap) wq->items[at] = (unsigned long long)i;
                 }
                 if (WITH_LLH) {
                     // llh.py:109-112: fr -> fr_to_angles -> (Gaussian substitute) angles_to_fr is the
@@ -127,6 +137,55 @@ __global__ __launch_bounds__(GF_BLOCK, CHECK_UNI ? 2 : GF_BSM_WAVES) void k_bsm(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Tier 2 for the walkers the evaluation kernel queued (UNI_DEFER): the fp64 estimate of the bins tier 1 does not clear,
+// one lane per walker, full waves of them -- instead of every wave of the evaluation running tier 2 because one of its
+// 64 walkers needs it.  Same classification as the inline path: condemned walkers get NON_UNITARY (and a NaN value),
+// undecided (walker, bin) pairs go on to the arbitration queue.
+__global__ __launch_bounds__(GF_BLOCK, 2) void k_bsm_tier2(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
+                                                           const double* __restrict__ theta, int layout, int64_t n,
+                                                           double* __restrict__ lnprob, int32_t* __restrict__ status,
+                                                           GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
+{
+    const GfCommon& c = *cp;
+    __shared__ __attribute__((aligned(16))) double rows[GF_BLOCK][GF_MAX_DIM];
+    __shared__ __attribute__((aligned(16))) double ttab[20];
+    if (threadIdx.x < 18) {
+        const int k = threadIdx.x, e = k >> 1;
+        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
+        const bool im = e == 4 || e == 6 || e == 8;
+        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
+        ttab[k] = srcp[idx];
+    }
+    __syncthreads();
+    const int ndim = c.ndim;
+    const unsigned int count = wq->count < wq->cap ? wq->count : wq->cap;
+    double* row = rows[threadIdx.x];
+    for (unsigned int q = blockIdx.x * GF_BLOCK + threadIdx.x; q < count; q += gridDim.x * GF_BLOCK) {
+        const int64_t i = (int64_t)wq->items[q];
+        if (i >= n) continue;
+        for (int d = 0; d < ndim; ++d) row[d] = layout == 0 ? theta[i * ndim + d] : theta[(int64_t)d * n + i];
+        UniAcc acc = {0.0, 0.0, 0ull, 2.0};
+        double fr[3];
+        flux_average<UNI_ONLY, 1>(c, tb, ttab, row, fr, acc);
+        if (!(acc.clear_max < tb->uni_hi)) {
+            status[i] = ST_NON_UNITARY;
+            if (lnprob) lnprob[i] = gf_nan();
+        } else if (acc.amb != 0) {
+            queue_pairs(uq, i, acc.amb);
+        }
+    }
+    // the last block to finish re-arms the walker queue for the next launch on this stream
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&wq->done, 1u) == gridDim.x - 1) {
+            wq->count = 0;
+            wq->done = 0;
+            __threadfence();
+        }
     }
 }
 
@@ -159,26 +218,33 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 
 template <int NDIM, int LPW>
 hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase, int cus, hipStream_t s)
+                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int cus, hipStream_t s)
 {
     const int grid = grid_for(n * LPW, GF_BLOCK, cus);
     const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * GF_FGRP_DOUBLES(nbins, LPW) * sizeof(double) : 0;
-    const bool chk = status != nullptr;
-#define GF_GO(WL, CU) hipLaunchKernelGGL((k_bsm<NDIM, WL, CU, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status, uq, qbase)
-    if (with_llh) { if (chk) GF_GO(true, true); else GF_GO(true, false); }
-    else          { if (chk) GF_GO(false, true); else GF_GO(false, false); }
+    // status requested: tiers 1-2 inline (wq == NULL) or deferred to k_bsm_tier2 (large batches, one lane per walker)
+    const int mode = status == nullptr ? UNI_NONE : (wq != nullptr && LPW == 1 ? UNI_DEFER : UNI_INLINE);
+#define GF_GO(WL, UM) hipLaunchKernelGGL((k_bsm<NDIM, WL, UM, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status, uq, wq)
+    if (with_llh) { if (mode == UNI_NONE) GF_GO(true, UNI_NONE); else if (mode == UNI_INLINE) GF_GO(true, UNI_INLINE); else { if constexpr (LPW == 1) GF_GO(true, UNI_DEFER); } }
+    else          { if (mode == UNI_NONE) GF_GO(false, UNI_NONE); else if (mode == UNI_INLINE) GF_GO(false, UNI_INLINE); else { if constexpr (LPW == 1) GF_GO(false, UNI_DEFER); } }
 #undef GF_GO
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && mode == UNI_DEFER) {
+        const int g2 = grid_for(n / 4 + 1, GF_BLOCK, cus);
+        hipLaunchKernelGGL(k_bsm_tier2, dim3(g2), dim3(GF_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, with_llh ? lnprob : nullptr, status, uq, wq);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 template <int NDIM>
 hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
-                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase, int cus, hipStream_t s)
+                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int cus, hipStream_t s)
 {
     switch (lanes_for(n, nbins, cus, status != nullptr)) {
-    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
-    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
-    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, cus, s);
+    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, cus, s);
+    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
     }
 }
 
@@ -188,30 +254,32 @@ hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_
 // whole batch and `n` = its size).  `uq` (status requested): where undecided (walker, bin) pairs go; `qbase` is added to
 // the walker index in the queue.
 static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta,
-                              int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t qbase,
+                              int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq,
                               int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
-    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
-    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, qbase, cus, s);
+    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
+    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
+    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
     }
 }
 
-// `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested.  With a status array
+// `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested; `wq`: its queue of
+// walkers for k_bsm_tier2 (capacity >= uq_cap / nbins walkers), NULL = tiers inline.  With a status array
 // an AoS batch is cut into pieces whose worst case (every bin of every walker undecided) fits the queue, each piece
 // followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, int cus, hipStream_t s)
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq,
+                         int cus, hipStream_t s)
 {
-    if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, 0, cus, s);
+    if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
     if (piece < 1) piece = 1;
     if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n
     for (int64_t w0 = 0; w0 < n; w0 += piece) {
         const int64_t m = n - w0 < piece ? n - w0 : piece;
         hipError_t e = launch_eval(c, d_common, d_bsm, nbins, ptab, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, with_llh,
-                                   lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, 0, cus, s);
+                                   lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, wq, cus, s);
         if (e != hipSuccess) return e;
         e = gf_launch_uni_resolve(d_common, d_bsm, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, c.ndim,
                                   with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, m * nbins, cus, s);

@@ -34,7 +34,15 @@ struct UniAcc {
     double est_max;             // largest estimate over the bins tier 1 did not clear
     double clear_max;           // ... over those of them where the estimate may condemn (a >= uni_a_lin)
     unsigned long long amb;     // bins whose estimate reaches uni_lo
+    double a_min;               // smallest SM weight over the bins (UNI_DEFER: what tier 1 needs, the rest runs later)
 };
+
+// How much of the unitarity verdict a call of flux_average / bin_moduli carries besides the values:
+constexpr int UNI_NONE = 0;     // values only
+constexpr int UNI_INLINE = 1;   // values + tiers 1 and 2 (small batches, the device sampler)
+constexpr int UNI_DEFER = 2;    // values + the smallest SM weight: the evaluation kernel of a large batch queues the few
+                                // walkers tier 1 does not clear for k_bsm_tier2 instead of making every wave run tier 2
+constexpr int UNI_ONLY = 3;     // tiers 1 and 2 without the values (k_bsm_tier2)
 
 struct Herm3 {          // 3x3 Hermitian: real diagonal + the three upper off-diagonals
     double d0, d1, d2;
@@ -161,13 +169,16 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 // (fr.py:204-214 with a = -1), moduli by the eigenvector-eigenvalue identity for the 2x2 block
 // (alpha, i) in {e, mu} x {0, 1}; the remaining five follow from the unit row and column sums of |U|^2.
 // Optionally the reference's eigenvector form for the unitarity status.
-template <bool CHECK_UNI>
+template <int UNI_MODE>
 __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
                                            double p[3][3], UniAcc& acc, int kbin, const GfBsm* __restrict__ tb)
 {
+    constexpr bool CHECK_UNI = UNI_MODE == UNI_INLINE || UNI_MODE == UNI_ONLY;
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
     const double a = al * s, t = be * s;
+    if (UNI_MODE == UNI_DEFER) acc.a_min = fmin(acc.a_min, a);
+    if (UNI_MODE == UNI_ONLY && !(a < tb->uni_a_ok)) return;          // tier 1 clears this bin: nothing to evaluate
     const double aa = a * a, at = a * t, tt = t * t;
     const double b = fma(aa, w.bS, fma(at, w.bSN, tt * w.bN));
     const double det = at * fma(a, w.m1, t * w.m2);
@@ -259,7 +270,7 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
 // per-bin compositions meet in LDS (`fgrp`: GF_FGRP_DOUBLES(nb, LPW) doubles, private to the lane group) and
 // every lane then runs the same in-order weighted sum, so the result is bitwise the LPW = 1 result on all LPW
 // lanes.  The walker's critical path drops from nb bins to ceil(nb / LPW).
-template <bool CHECK_UNI, int LPW = 1>
+template <int UNI_MODE, int LPW = 1>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
                                              const double* row, double fr[3], UniAcc& acc, int sub = 0,
                                              double* fgrp = nullptr)
@@ -299,7 +310,8 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
-        bin_moduli<CHECK_UNI>(w, Sn, Nn, u, v, p, acc, k, tb);
+        bin_moduli<UNI_MODE>(w, Sn, Nn, u, v, p, acc, k, tb);
+        if (UNI_MODE == UNI_ONLY) continue;                             // the verdict only: no composition
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
         const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
         const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
@@ -315,7 +327,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         }
     }
     if (LPW > 1) {
-        if (CHECK_UNI) {
+        if (UNI_MODE == UNI_INLINE) {
             fgrp[3 * nb + sub] = acc.est_max;
             fgrp[3 * nb + LPW + sub] = acc.clear_max;
             fgrp[3 * nb + 2 * LPW + sub] = __longlong_as_double((long long)acc.amb);
@@ -328,7 +340,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
             const double wk = tb->weight[k];
             a0 = fma(fgrp[3 * k], wk, a0); a1 = fma(fgrp[3 * k + 1], wk, a1); a2 = fma(fgrp[3 * k + 2], wk, a2);
         }
-        if (CHECK_UNI) {
+        if (UNI_MODE == UNI_INLINE) {
 #pragma unroll
             for (int j = 0; j < LPW; ++j) {
                 acc.est_max = fmax(acc.est_max, fgrp[3 * nb + j]);

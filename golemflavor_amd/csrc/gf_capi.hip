@@ -125,6 +125,7 @@ struct gf_model {
     size_t cube_cap = 0;
     // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
     GfUniQueue* d_uq = nullptr;
+    GfUniQueue* d_wq = nullptr;  // walkers for the deferred tier 2 (same lifetime as d_uq; capacity uq_cap / nbins)
     int64_t uq_cap = 0;
     GfUniQueue h_uq_hdr = {0, 0, 0, 0, {0}};
     std::mutex call_mu;          // serialises the entry points that use the model's staging buffers / queue
@@ -248,6 +249,8 @@ int check_dev_ptr(const void* p, size_t align)
 // The arbitration queue must hold every (walker, bin) pair of one piece of the batch (gf_launch_bsm cuts AoS batches
 // into pieces of uq_cap / nbins walkers; SoA batches go in one piece).
 constexpr int64_t UQ_MAX_ITEMS = 1 << 24;      // 128 MB of items: ~840 k walkers x 20 bins per piece
+// from this batch size on (one lane per walker in the evaluation kernel) tier 2 runs as its own compact kernel
+constexpr int64_t GF_TIER2_SPLIT_MIN = 65536;
 
 int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
 {
@@ -263,10 +266,16 @@ int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
     while (cap < need) cap *= 2;
     GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
     if (m->d_uq) (void)hipFree(m->d_uq);
-    m->d_uq = nullptr; m->uq_cap = 0;
+    if (m->d_wq) (void)hipFree(m->d_wq);
+    m->d_uq = nullptr; m->d_wq = nullptr; m->uq_cap = 0;
+    const int64_t wcap = cap / nb + 1;
     GF_HIP(hipMalloc((void**)&m->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
+    GF_HIP(hipMalloc((void**)&m->d_wq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)wcap));
     m->h_uq_hdr.count = 0; m->h_uq_hdr.done = 0; m->h_uq_hdr.cap = (unsigned int)cap; m->h_uq_hdr.pad_ = 0;
     GF_HIP(hipMemcpyAsync(m->d_uq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
+    GF_HIP(hipStreamSynchronize(st));
+    m->h_uq_hdr.cap = (unsigned int)wcap;
+    GF_HIP(hipMemcpyAsync(m->d_wq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
     GF_HIP(hipStreamSynchronize(st));
     m->uq_cap = cap;
     return GF_OK;
@@ -280,7 +289,7 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->cus, st);
     }
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
@@ -295,7 +304,7 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->cus, st);
     }
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
@@ -586,6 +595,7 @@ void gf_model_destroy(gf_model* m)
     if (m->h_pin) (void)hipHostFree(m->h_pin);
     if (m->d_cube) (void)hipFree(m->d_cube);
     if (m->d_uq) (void)hipFree(m->d_uq);
+    if (m->d_wq) (void)hipFree(m->d_wq);
     delete m;
 }
 

@@ -102,8 +102,8 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
         val = -gf_inf();
         st = ST_OUT_OF_PRIOR;
         if (inbox) {
-            UniAcc acc = {0.0, 0.0, 0ull};
-            flux_average<true, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
+            UniAcc acc = {0.0, 0.0, 0ull, 2.0};
+            flux_average<UNI_INLINE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
             st = (acc.est_max < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;      // tiers 1 and 2 (gf_bsm_device.hpp)
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;

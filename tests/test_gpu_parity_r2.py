@@ -272,3 +272,32 @@ def test_unitarity_verdict_through_the_transition(golden, oracle):
         nagree_band += int((flagged == (ref_st[sel] == 2))[~dec].sum())
     assert ndec >= 700 and nband >= 5
     assert nagree_band >= 0.6 * nband
+
+
+def test_deferred_tier2_equals_inline(oracle):
+    """From 65 536 walkers per call on, tier 2 of the unitarity verdict runs as its own compact kernel on the walkers tier 1
+    does not clear (k_bsm_tier2) instead of inside the evaluation kernel: status and values must be those of the
+    inline path, which the other tests pin on the oracle -- bit for bit, through the failing region of texture OEU."""
+    from common import uniform_theta
+    dim, tex = 6, Texture.OEU
+    _, ps = Cf.fr_paramsets(dim, (0.4, 0.0))
+    lo, hi = Cf.SCALE_BOUNDARIES[dim]
+    rng = np.random.default_rng(99)
+    n = 70000
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[:, -1] = rng.uniform(lo, hi, n)
+    kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(1 / 3, 2 / 3, 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    with Model(compile_model(ps, "BSM_GAUSS", texture=tex, **kw)) as m:
+        lp_big, fr_big, st_big = m.lnprob(th, want_fr=True)                       # one call: deferred
+        pfr_big, pst_big = m.propagate(th)
+        parts = [m.lnprob(th[i:i + 7000], want_fr=True) for i in range(0, n, 7000)]   # ten calls: inline
+    lp = np.concatenate([p[0] for p in parts]); st = np.concatenate([p[2] for p in parts])
+    assert np.array_equal(st_big, st) and np.array_equal(pst_big, st)
+    assert np.array_equal(lp_big, lp, equal_nan=True)
+    assert 0.1 < np.mean(st == _lib.GF_ST_NON_UNITARY) < 0.3 and np.isnan(lp_big[st == _lib.GF_ST_NON_UNITARY]).all()
+    # and against the oracle on a sample
+    om = oracle.make_model(ps, "BSM_GAUSS", texture=tex.name, **kw)
+    pick = rng.choice(n, 3000, replace=False)
+    r80 = oracle.unitarity_residual_batch(om, th[pick])
+    dec = _decided(r80)
+    assert np.array_equal((st_big[pick] == _lib.GF_ST_NON_UNITARY)[dec], (r80 >= 1e-7)[dec])
