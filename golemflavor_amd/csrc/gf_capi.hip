@@ -248,7 +248,8 @@ int check_dev_ptr(const void* p, size_t align)
 
 // The arbitration queue must hold every (walker, bin) pair of one piece of the batch (gf_launch_bsm cuts AoS batches
 // into pieces of uq_cap / nbins walkers; SoA batches go in one piece).
-constexpr int64_t UQ_MAX_ITEMS = 1 << 24;      // 128 MB of items: ~840 k walkers x 20 bins per piece
+constexpr int64_t UQ_MAX_ITEMS = 1 << 27;      // 1 GiB of items at most: ~6.7 M walkers x 20 bins per piece (allocated only
+                                               // when a status array is asked for on a batch that large; 288 GB of HBM)
 // from this batch size on (one lane per walker in the evaluation kernel) tier 2 runs as its own compact kernel
 constexpr int64_t GF_TIER2_SPLIT_MIN = 65536;
 

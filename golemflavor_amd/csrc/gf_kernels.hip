@@ -148,6 +148,47 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
     if (i_prev >= 0) GF_STORE_OUT(lnprob + i_prev, val_prev);
 }
 
+// SoA theta ([ndim][n], one contiguous column per parameter): every lane reads its own walker's NDIM values with
+// lane-contiguous 8-B loads (512 B per wave-instruction, each 128-B line used once) straight into registers -- no LDS
+// tile, no transposition.  Same software pipeline as the AoS kernel: the next tile's loads are in flight while the
+// current one is evaluated.  Full 64-walker tiles; the launcher hands the remainder to k_lnprob_sm_gen.  SAMPLED is 2
+// (canonical columns: the row registers are used by position) or 0 for MODE_PRIOR_ONLY; posteriors that read named
+// columns through a runtime index stay on the generic kernel (a register array cannot be indexed dynamically).
+template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
+__global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_soa(const GfCommon c, const double* __restrict__ ptab,
+                                                             const double* __restrict__ theta, int64_t n, int64_t nfull,
+                                                             double* __restrict__ lnprob, double* __restrict__ fr_out,
+                                                             int32_t* __restrict__ status)
+{
+    static_assert(NDIM > 0, "compile-time row length");
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4];
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / GF_WAVE);
+    const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
+    int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave;
+    if (t >= nfull) return;
+    double pre[NDIM];
+#pragma unroll
+    for (int d = 0; d < NDIM; ++d) pre[d] = GF_LOAD_THETA(theta + (int64_t)d * n + t * GF_WAVE + lane);
+    for (; t < nfull; t += stride) {
+        double row[NDIM];
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) row[d] = pre[d];
+        const int64_t tn = (t + stride < nfull) ? t + stride : t;       // past the end: a harmless re-read of this tile
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) pre[d] = GF_LOAD_THETA(theta + (int64_t)d * n + tn * GF_WAVE + lane);
+        const int64_t i = t * GF_WAVE + lane;
+        double val, fr[3];
+        int st;
+        eval_walker<NDIM, MODE, SAMPLED, WANT_FR>(c, ctab, row, NDIM, val, fr, st);
+        GF_STORE_OUT(lnprob + i, val);
+        if (WANT_FR) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
+        if (status) status[i] = st;
+    }
+}
+
 #if defined(GF_ASM_PIPE) || defined(GF_EXPERIMENTAL_RING)
 #include "../../tools/experiments/gf_sm_experiments.hpp"   // measured alternatives, not built by default
 #endif
@@ -378,6 +419,21 @@ hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const doub
 #undef GF_GO
             first = nfull * GF_WAVE;
             }
+        }
+    }
+    if constexpr (NDIM != 0) {
+        // SoA: the register kernel for the posteriors that read their columns by position
+        int64_t nfull = n / GF_WAVE;
+        if (n <= 2048 && n % GF_WAVE != 0) nfull = 0;
+        const bool canon = NDIM >= 6 && c.idx_sm[0] == 0 && c.idx_sm[1] == 1 && c.idx_sm[2] == 2 && c.idx_sm[3] == 3 &&
+                           c.idx_src[0] == 4 && c.idx_src[1] == 5;
+        if (layout == 1 && nfull > 0 && (MODE == MODE_PRIOR_ONLY || canon)) {
+            const int grid = grid_for(nfull * GF_WAVE, GF_BLOCK, cus);
+#define GF_GOS(S, F) hipLaunchKernelGGL((k_lnprob_sm_soa<NDIM, MODE, S, F>), dim3(grid), dim3(GF_BLOCK), 0, s, c, ptab, theta, n, nfull, lnprob, fr, status)
+            if (MODE == MODE_PRIOR_ONLY) { if (fr) GF_GOS(0, true); else GF_GOS(0, false); }
+            else                         { if (fr) GF_GOS(2, true); else GF_GOS(2, false); }
+#undef GF_GOS
+            first = nfull * GF_WAVE;
         }
     }
     if (first < n) {

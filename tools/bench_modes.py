@@ -56,7 +56,7 @@ for name, ps, kw, want_fr, want_st in cases:
         print(json.dumps({"case": name, "ndim": nd, "bytes_per_eval": b, "kernel_ms": round(ms, 4), "evals_per_s": N / ms * 1e3,
                           "GBps_algorithmic": N * b / ms / 1e6, "frac_hbm_peak": round(N * b / ms / 1e6 / 8000, 3)}), flush=True)
 
-# the same notebook posterior from an SoA buffer ([ndim][n]); goes through the generic kernel
+# the same notebook posterior from an SoA buffer ([ndim][n]): k_lnprob_sm_soa (per-lane coalesced column loads, no LDS tile)
 name, ps, kw = cases[0][0], cases[0][1], dict(cases[0][2])
 mode = kw.pop("mode")
 box = np.array(ps.seeds, dtype=float)
@@ -73,5 +73,5 @@ with Model(compile_model(ps, mode, **kw)) as m:
         m.lnprob_device(d_th.ptr, N, d_out.ptr, None, None, layout=1)
     e1.record(); m.sync()
     ms = e0.elapsed_ms(e1) / 20
-    print(json.dumps({"case": name + " (SoA input, generic kernel)", "ndim": 6, "bytes_per_eval": 56, "kernel_ms": round(ms, 4),
+    print(json.dumps({"case": name + " (SoA input, register kernel)", "ndim": 6, "bytes_per_eval": 56, "kernel_ms": round(ms, 4),
                       "evals_per_s": N / ms * 1e3, "GBps_algorithmic": N * 56 / ms / 1e6, "frac_hbm_peak": round(N * 56 / ms / 1e6 / 8000, 3)}))
