@@ -63,7 +63,10 @@ struct StretchArgs {
     double* pos;            // [nchains][nwalkers][ndim]
     double* lnp;            // [nchains][nwalkers]
     uint32_t* naccept;      // [nchains][nwalkers]
-    uint32_t* flags;        // [0]: walkers whose proposal came back NON_UNITARY (reference would raise)
+    uint32_t* flags;        // [0]: proposals the estimate condemns (NON_UNITARY: the reference would raise); [1]: proposals
+                            // whose verdict the estimate cannot settle -- evaluated as unitary and logged for the exact check
+    double* pend_log;       // [pend_cap][1 + GF_MAX_DIM]: chain index, then the proposal's theta
+    uint32_t pend_cap;
     double* chain;          // [nchains][nstore_cap][nwalkers][ndim] or null
     double* lnp_chain;      // [nchains][nstore_cap][nwalkers] or null
     int64_t nstore_cap;
@@ -90,11 +93,15 @@ __global__ void k_tick(StepState* st, int nsteps)
 }
 
 // lnprob of the proposal held in LDS row `row`
+// `pending`: the unitarity verdict of this proposal is not settled by the in-kernel tiers (gf_bsm_device.hpp): it is
+// evaluated as unitary here and its theta logged; the exact (x87-faithful) verdict is taken afterwards through the bulk
+// path (mcmc.DeviceEnsembleSampler._check_flags), which is where a reference run would have died.
 template <int NDIM, int MODE, int LPW>
 __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm* tb, const double* ctab,
                                                   const double* ttab, const double* row, int ndim, int& st, int sub,
-                                                  double* fgrp)
+                                                  double* fgrp, bool& pending)
 {
+    pending = false;
     double val, fr[3];
     if (MODE == MODE_BSM_GAUSS) {
         double lp;
@@ -104,7 +111,8 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
         if (inbox) {
             UniAcc acc = {0.0, 0.0, 0ull, 2.0};
             flux_average<UNI_INLINE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
-            st = (acc.est_max < UNI_THRESHOLD) ? ST_OK : ST_NON_UNITARY;      // tiers 1 and 2 (gf_bsm_device.hpp)
+            st = (acc.clear_max < tb->uni_hi) ? ST_OK : ST_NON_UNITARY;       // tiers 1 and 2 (gf_bsm_device.hpp)
+            pending = st == ST_OK && acc.amb != 0;
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;
         }
@@ -172,7 +180,16 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
         row[d] = fma(-z, cv - sk[d], cv);                    // q = c_j - z (c_j - s_k)
     }
     int st;
-    const double lnq = proposal_lnprob<NDIM, MODE, LPW>(c, tb, ctab, ttab, row, ndim, st, sub, fgrp);
+    bool pending;
+    const double lnq = proposal_lnprob<NDIM, MODE, LPW>(c, tb, ctab, ttab, row, ndim, st, sub, fgrp, pending);
+    if (MODE == MODE_BSM_GAUSS && pending && sub == 0) {
+        const uint32_t at = atomicAdd(s.flags + 1, 1u);
+        if (at < s.pend_cap) {
+            double* dst = s.pend_log + (size_t)at * (1 + GF_MAX_DIM);
+            dst[0] = (double)chain;
+            for (int d = 0; d < ndim; ++d) dst[1 + d] = row[d];
+        }
+    }
     const int64_t wi = (int64_t)chain * s.nwalkers + w;
     const double lnk = s.lnp[wi];
     // z^(ndim-1) / u3
@@ -340,7 +357,8 @@ __global__ __launch_bounds__(1024) void k_stretch_persist(const PersistArgs s)
                     row[d] = fma(-z, cv - sk[d], cv);
                 }
                 int st;
-                const double lnq = proposal_lnprob<NDIM, MODE, 1>(c, nullptr, ctab, nullptr, row, ndim, st, 0, nullptr);
+                bool pending;
+                const double lnq = proposal_lnprob<NDIM, MODE, 1>(c, nullptr, ctab, nullptr, row, ndim, st, 0, nullptr, pending);
                 const double lnk = lnp[w];
                 double zp = 1.0;
                 for (int d = 1; d < ndim; ++d) zp *= z;
@@ -475,6 +493,8 @@ struct gf_sampler {
     double* d_lnp = nullptr;
     uint32_t* d_naccept = nullptr;
     uint32_t* d_flags = nullptr;
+    double* d_pend_log = nullptr;       // proposals whose unitarity verdict needs the exact evaluation (BSM posteriors)
+    uint32_t pend_cap = 0;
     double* d_chain = nullptr;
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
@@ -541,6 +561,10 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_lnp, sizeof(double) * nw);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_naccept, sizeof(uint32_t) * nw);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, sizeof(uint32_t) * 4);
+    if (e == hipSuccess && c->mode == MODE_BSM_GAUSS) {
+        s->pend_cap = 16384;
+        e = hipMalloc((void**)&s->d_pend_log, sizeof(double) * (size_t)s->pend_cap * (1 + GF_MAX_DIM));
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_state, sizeof(StepState));
     // every transfer of this file goes through the sampler's stream: a synchronous (null-stream) hipMemcpy / hipMemset
     // issued while ANOTHER host thread is capturing its sampler's graph fails and poisons that capture on this runtime
@@ -571,6 +595,7 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_lnp) (void)hipFree(s->d_lnp);
     if (s->d_naccept) (void)hipFree(s->d_naccept);
     if (s->d_flags) (void)hipFree(s->d_flags);
+    if (s->d_pend_log) (void)hipFree(s->d_pend_log);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->d_chain) (void)hipFree(s->d_chain);
@@ -740,6 +765,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     StretchArgs a;
     a.state = s->d_state;
     a.pos = s->d_pos; a.lnp = s->d_lnp; a.naccept = s->d_naccept; a.flags = s->d_flags;
+    a.pend_log = s->d_pend_log; a.pend_cap = s->pend_cap;
     a.chain = store ? s->d_chain : nullptr;
     a.lnp_chain = store ? s->d_lnp_chain : nullptr;
     a.nstore_cap = s->nstore_cap; a.seed = s->seed; a.nchains = s->nchains; a.nwalkers = s->nwalkers; a.a = s->a;
@@ -912,6 +938,29 @@ int gf_sampler_get_chain_device(gf_sampler* s, double* d_chain, double* d_lnprob
                                      s->nchains, hipMemcpyDeviceToDevice, st));
     }
     GFS_HIP(hipStreamSynchronize(st));
+    return GF_OK;
+}
+
+// Proposals (since the last reset) whose unitarity verdict the in-kernel tiers could not settle: *count = how many,
+// rows [min(count, cap)][1 + GF_MAX_DIM] = chain index then theta (NULL = count only).  They were evaluated as unitary; the
+// caller takes their exact verdict through gf_lnprob_batch with a status array (the x87-faithful arbitration) and, like
+// the reference, lets the run die if one of them fails.
+int gf_sampler_pending(gf_sampler* s, uint32_t* count, double* rows, uint32_t cap)
+{
+    if (!s || !count) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t fl[2] = {0, 0};
+    GFS_HIP(hipMemcpyAsync(fl, s->d_flags, sizeof(fl), hipMemcpyDeviceToHost, st));
+    GFS_HIP(hipStreamSynchronize(st));
+    *count = fl[1];
+    uint32_t n = fl[1] < s->pend_cap ? fl[1] : s->pend_cap;
+    if (n > cap) n = cap;
+    if (rows && n > 0 && s->d_pend_log) {
+        GFS_HIP(hipMemcpyAsync(rows, s->d_pend_log, sizeof(double) * (size_t)n * (1 + GF_MAX_DIM), hipMemcpyDeviceToHost, st));
+        GFS_HIP(hipStreamSynchronize(st));
+    }
     return GF_OK;
 }
 

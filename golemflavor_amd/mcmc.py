@@ -258,6 +258,7 @@ class DeviceEnsembleSampler:
 
     def reset(self):
         self._lib.check(self._L.gf_sampler_reset(self._h), "gf_sampler_reset")
+        self._pend_seen, self._pend_bad = 0, 0
 
     def run_mcmc(self, pos0, N, thin=1, storechain=True):
         """Advance N steps (asynchronous launches, then one sync); returns (pos, lnprob, None)."""
@@ -303,12 +304,39 @@ class DeviceEnsembleSampler:
             for _ in range(m):
                 yield pos, lnp, None
 
+    PEND_CAP = 16384
+
     def _check_flags(self):
-        n = (self._C.c_uint32 * 1)()
+        """Non-unitary proposals since the last reset.  The kernels settle the verdict of almost every proposal
+        themselves (csrc/gf_bsm_device.hpp, tiers 1-2); the few they cannot were evaluated as unitary and logged, and
+        get their exact verdict here through the bulk path (x87-faithful arbitration).  Reference behaviour: the run
+        dies on the first such proposal (fr.py:493-498)."""
+        C = self._C
+        n = (C.c_uint32 * 1)()
         self._lib.check(self._L.gf_sampler_get_chain(self._h, None, None, None, n), "gf_sampler_get_chain")
-        if n[0] and self.on_nonunitary == "raise":
+        bad = int(n[0])
+        cnt = C.c_uint32(0)
+        self._lib.check(self._L.gf_sampler_pending(self._h, C.byref(cnt), None, 0), "gf_sampler_pending")
+        seen = getattr(self, "_pend_seen", 0)
+        if cnt.value < seen:                                   # the sampler was reset
+            seen, self._pend_bad = 0, 0
+        if cnt.value > seen and seen < self.PEND_CAP:
+            m = min(cnt.value, self.PEND_CAP)
+            rows = np.empty((m, 1 + self._lib.GF_MAX_DIM))
+            self._lib.check(self._L.gf_sampler_pending(self._h, C.byref(cnt), rows.ctypes.data_as(self._lib._dp), m),
+                            "gf_sampler_pending")
+            new = rows[seen:m]
+            for ch in np.unique(new[:, 0]).astype(int):
+                model = self.models[ch] if self.models is not None else self.model
+                th = np.ascontiguousarray(new[new[:, 0] == ch][:, 1:1 + self.dim])
+                st = model.lnprob(th)[1]
+                self._pend_bad = getattr(self, "_pend_bad", 0) + int(np.sum(st == self._lib.GF_ST_NON_UNITARY))
+            self._pend_seen = cnt.value
+        bad += getattr(self, "_pend_bad", 0)
+        self.nonunitary_proposals = bad
+        if bad and self.on_nonunitary == "raise":
             # reference: AssertionError out of test_unitarity kills the run (fr.py:493-498)
-            raise AssertionError("Matrix is not unitary! (%d proposals)" % n[0])
+            raise AssertionError("Matrix is not unitary! (%d proposals)" % bad)
 
     # -- results --------------------------------------------------------------------------
     @property

@@ -63,3 +63,30 @@ for k, cs in summary.items():
                    "raw_WRITE_SIZE_KiB": cs["WRITE_SIZE"],
                    "note": "FETCH_SIZE x1024 x2 (gfx950 wide-load correction) + WRITE_SIZE x1024; separate --pmc passes"},
                   open(os.path.join(out, "traffic.json"), "w"), indent=1)
+
+# BSM kernel: VALU wave-instructions per walker from SQ_INSTS_VALU of the largest dispatches (tools/bench_bsm.py runs
+# n = 4 194 304 walkers: 65 536 wave-tiles) -> profiles/bsm_instr.json, which bench.py turns into a fraction of the fp64
+# issue rate.  One file per run directory; copy it to profiles/ to make it the committed constant.
+big = defaultdict(lambda: defaultdict(list))
+for r in rows("pmc_sq/**/*counter_collection.csv"):
+    if "k_bsm<" in r["Kernel_Name"] and r["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
+        big[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+instr = {}
+N_BIG = 4 * 1024 * 1024
+for (k, grid), cs in big.items():
+    if grid != 524288 or "SQ_INSTS_VALU" not in cs:
+        continue
+    import re
+    m = re.search(r"k_bsm<(\d+), (true|false), (\d), 1>", k)
+    if not m:
+        continue
+    valu = sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"])
+    # status variants run in pieces: a dispatch covers N_BIG walkers only when SQ_INSTS_VALU says so; use waves x tiles
+    key = "%s_%s" % (m.group(1), "no_status" if m.group(3) == "0" else "with_status")
+    if m.group(3) == "0":
+        instr[key] = {"kernel": k[:70], "valu_wave_instr_per_launch": valu, "walkers_per_launch": N_BIG,
+                      "valu_wave_instr_per_walker": valu / (N_BIG / 64.0), "valu_instr_per_bin_incl_prologue": valu / (N_BIG / 64.0) / 20.0}
+if instr:
+    instr["note"] = "rocprofv3 --pmc SQ_INSTS_VALU, tools/bench_bsm.py, dispatches of 4 194 304 walkers (grid 524288), 20 energy bins"
+    json.dump(instr, open(os.path.join(out, "bsm_instr.json"), "w"), indent=1)
+    print("bsm_instr:", json.dumps(instr))

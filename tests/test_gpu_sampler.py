@@ -5,6 +5,7 @@ import pytest
 from common import BIN_EDGES, bsm_args, notebook_sets, uniform_theta
 from golemflavor_amd import _lib
 from golemflavor_amd import configs as Cf
+from golemflavor_amd import fr as fr_utils
 from golemflavor_amd import llh as llh_utils
 from golemflavor_amd import mcmc as mcmc_utils
 from golemflavor_amd.enums import Texture
@@ -484,3 +485,41 @@ def test_multinest_style_cube_adapter(golden, oracle):
     f.close()
 
 
+
+
+def test_bsm_sampler_unitarity_through_the_failing_region():
+    """A 12-column chain of texture OEU seeded across the top of its scale range, where the reference's unitarity assert
+    fires (fr.py:461-499).  The stretch kernels settle most proposals in-kernel (SM-weight bound, fp64 estimate); the ones
+    they cannot are evaluated as unitary, logged, and judged exactly afterwards through the bulk path.  `raise` (the
+    reference's behaviour): the run dies; `-inf`: it completes and reports how many proposals a reference run would have
+    died on -- at least the ones the estimate condemned outright."""
+    import ctypes as C
+    inj = fr_utils.fr_to_angles((1, 1, 1))
+    asimov, ps = Cf.fr_paramsets(6, inj)
+    args = bsm_args(6, Texture.OEU, (1 / 3, 2 / 3, 0.))
+    rng = np.random.default_rng(4)
+    box = np.array(ps.seeds, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(64, 12))
+    p0[:, 11] = rng.uniform(-40.0, -30.0, 64)
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.3, on_nonunitary="-inf")
+    smp = mcmc_utils.DeviceEnsembleSampler(64, 12, f, seed=11)
+    smp.run_mcmc(p0, 40)
+    n = (C.c_uint32 * 1)()
+    _lib.check(smp._L.gf_sampler_get_chain(smp._h, None, None, None, n), "flags")
+    cnt = C.c_uint32(0)
+    _lib.check(smp._L.gf_sampler_pending(smp._h, C.byref(cnt), None, 0), "pending")
+    assert n[0] > 0 and cnt.value > 0                       # both kinds occur in this region
+    assert smp.nonunitary_proposals >= n[0]
+    # the logged proposals: their exact verdict through the bulk path is what _check_flags added
+    rows = np.empty((min(cnt.value, 16384), 1 + _lib.GF_MAX_DIM))
+    _lib.check(smp._L.gf_sampler_pending(smp._h, C.byref(cnt), rows.ctypes.data_as(_lib._dp), len(rows)), "pending rows")
+    st = f.model.lnprob(np.ascontiguousarray(rows[:, 1:13]))[1]
+    assert np.all(rows[:, 0] == 0) and smp.nonunitary_proposals == n[0] + int(np.sum(st == _lib.GF_ST_NON_UNITARY))
+    smp.close()
+    g = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.3)              # on_nonunitary="raise", the reference's behaviour
+    smp = mcmc_utils.DeviceEnsembleSampler(64, 12, g, seed=11)
+    with pytest.raises(AssertionError, match="not unitary"):
+        smp.run_mcmc(p0, 40)
+    smp.close()
+    f.close()
+    g.close()
