@@ -332,6 +332,24 @@ __global__ __launch_bounds__(GF_BLOCK) void k_flavor_hist(const double* __restri
     }
 }
 
+// Chain post-processing output rows: out[i] = (fr[i][0..3), theta[i][0..ndim)) -- the composition of a stored sample next to
+// the sample itself; status[i] != 0 (the reference would have raised on that sample, scripts/mc_texture.py:216-221 through
+// fr.py:398-399) turns the composition into NaN.  Pure data movement, one thread per output element.
+__global__ __launch_bounds__(GF_BLOCK) void k_join_rows(const double* __restrict__ fr, const int32_t* __restrict__ status,
+                                                        const double* __restrict__ theta, int ndim, int64_t n, double* __restrict__ out)
+{
+    const int w = 3 + ndim;
+    const int64_t total = n * w;
+    for (int64_t e = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * GF_BLOCK) {
+        const int64_t i = e / w;
+        const int col = (int)(e - i * w);
+        double v;
+        if (col < 3) v = (status && status[i] != 0) ? gf_nan() : fr[3 * i + col];
+        else v = theta[i * ndim + (col - 3)];
+        out[e] = v;
+    }
+}
+
 // MultiNest's unit cube -> theta (golemflavor/mn.py:33-39): the scanned columns are mapped onto their ranges,
 // theta_c = lo_c + (hi_c - lo_c) u, every other column keeps its current value.  One thread per (walker, column).
 struct CubeMap {
@@ -501,6 +519,14 @@ hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int la
     case 6: return launch_propagate_sm_n<6>(c, theta, layout, n, fr, status, cus, s);
     default: return launch_propagate_sm_n<0>(c, theta, layout, n, fr, status, cus, s);
     }
+}
+
+hipError_t gf_launch_join_rows(const double* fr, const int32_t* status, const double* theta, int ndim, int64_t n, double* out,
+                               int cus, hipStream_t s)
+{
+    const int grid = grid_for(n * (3 + ndim), GF_BLOCK, cus);
+    hipLaunchKernelGGL(k_join_rows, dim3(grid), dim3(GF_BLOCK), 0, s, fr, status, theta, ndim, n, out);
+    return hipGetLastError();
 }
 
 hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s)

@@ -24,6 +24,8 @@ hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBs
 // bounds the grid; the item count itself is read on the device.
 hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int ndim,
                                  double* lnprob, int32_t* status, GfUniQueue* uq, int64_t max_items, int cus, hipStream_t s);
+hipError_t gf_launch_join_rows(const double* fr, const int32_t* status, const double* theta, int ndim, int64_t n, double* out,
+                               int cus, hipStream_t s);
 hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s);
 hipError_t gf_launch_cube_to_theta(const GfCommon& c, int nscan, const int32_t* cols, const double* base, const double* cube,
                                    int64_t n, double* theta, int cus, hipStream_t s);

@@ -1035,6 +1035,41 @@ int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double
     return rc;
 }
 
+// The scan's output rows on the device: d_rows [nchains][nstored][nwalkers][3 + ndim] = composition (NaN where the
+// reference would have raised) then the sample, each chain propagated with models[ch] (NULL: the sampling models).
+// Synchronous on return.  scripts/mc_texture.py:216-223.
+int gf_sampler_postprocess_rows_device(gf_sampler* s, gf_model* const* models, double* d_rows)
+{
+    if (!s || !d_rows) return GF_ERR_INVALID_ARG;
+    const GfCommon* c0; const GfBsm* tb; const double* ptab; void* stream; int device0;
+    if (gf_model_internal(s->model, &c0, &tb, &ptab, &stream, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipSetDevice(device0));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per_chain = s->nstored * s->nwalkers;
+    if (per_chain == 0) { GFS_HIP(hipStreamSynchronize(st)); return GF_OK; }
+    double* d_fr = nullptr;
+    int32_t* d_st = nullptr;
+    GFS_HIP(hipMalloc((void**)&d_fr, sizeof(double) * 3 * per_chain * s->nchains));
+    {
+        hipError_t e_ = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain * s->nchains);
+        if (e_ != hipSuccess) { (void)hipFree(d_fr); return sfail(e_, "hipMalloc(status)"); }
+    }
+    int rc = gf_sampler_postprocess_device(s, models, d_fr, d_st);
+    hipError_t e = hipSuccess;
+    for (int ch = 0; ch < s->nchains && rc == GF_OK && e == hipSuccess; ++ch) {
+        const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
+        e = gf_launch_join_rows(d_fr + (size_t)ch * per_chain * 3, d_st + (size_t)ch * per_chain, d_theta, s->ndim, per_chain,
+                                d_rows + (size_t)ch * per_chain * (3 + s->ndim), s->cus, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_fr);
+    (void)hipFree(d_st);
+    if (rc != GF_OK) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess_rows_device");
+    return GF_OK;
+}
+
 int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
                                 uint64_t* counts)
 {

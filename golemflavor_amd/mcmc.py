@@ -438,6 +438,16 @@ class DeviceEnsembleSampler:
             handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
         self._lib.check(self._L.gf_sampler_postprocess_device(self._h, handles, d_fr, d_status), "gf_sampler_postprocess_device")
 
+    def postprocess_rows_to_device(self, d_rows, models=None):
+        """The rows a scan saves -- composition (NaN where the reference would have raised) then the sample -- assembled
+        on the device: d_rows [nchains][nstored][nwalkers][3 + ndim]."""
+        C = self._C
+        handles = None
+        if models is not None:
+            ms = [getattr(m, "model", m) for m in models]
+            handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
+        self._lib.check(self._L.gf_sampler_postprocess_rows_device(self._h, handles, d_rows), "gf_sampler_postprocess_rows_device")
+
     def flat_steps(self):
         """The stored samples in the order the device holds them, (nsteps*nwalkers, ndim) [leading chain axis
         when nchains > 1]: `flatchain` without the transposition to emcee's walker-major order -- for

@@ -109,7 +109,7 @@ class _SensPoint:
 
     @staticmethod
     def assemble(samples, frs, status):
-        return np.array(samples)
+        return samples                                       # the chain is the result: no copy
 
     def close(self):
         self.f.close()
@@ -210,27 +210,18 @@ class DeviceGather:
         slots = gdist.slots_per_rank(n_points, self.world)
         first = jobs[order[0]]
         per = sampler.nstored * first.nwalkers                    # samples per grid point
-        ndim = first.ndim
-        blk = slots * per * ndim * 8
-        d_chain = self.m.alloc(blk)                               # ranks with fewer points leave the tail unused
-        sampler.chain_to_device(d_chain.ptr)
-        chains = self._exchange(d_chain, blk, (self.world, slots, per, ndim), np.float64)
-        d_chain.free()
-        frs = sts = None
-        if first.post_model is not None:                          # mc_texture.py:216-221 on the device, gathered too
-            d_fr, d_st = self.m.alloc(slots * per * 3 * 8), self.m.alloc(slots * per * 4)
-            sampler.postprocess_to_device(d_fr.ptr, d_st.ptr, models=[jobs[g].post_model for g in order])
-            frs = self._exchange(d_fr, slots * per * 3 * 8, (self.world, slots, per, 3), np.float64)
-            sts = self._exchange(d_st, slots * per * 4, (self.world, slots, per), np.int32)
-            d_fr.free()
-            d_st.free()
+        width = first.ndim if first.post_model is None else 3 + first.ndim
+        blk = slots * per * width * 8
+        d_rows = self.m.alloc(blk)                                # ranks with fewer points leave the tail unused
+        if first.post_model is None:
+            sampler.chain_to_device(d_rows.ptr)
+        else:                                                     # mc_texture.py:216-223 on the device: (fr, sample) rows
+            sampler.postprocess_rows_to_device(d_rows.ptr, models=[jobs[g].post_model for g in order])
+        rows = self._exchange(d_rows, blk, (self.world, slots, per, width), np.float64)
+        d_rows.free()
         if self.rank != 0:
             return None
-        out = []
-        for g in range(n_points):
-            r, sl = g % self.world, g // self.world
-            out.append(first.assemble(chains[r, sl], None if frs is None else frs[r, sl], None if sts is None else sts[r, sl]))
-        return out
+        return [rows[g % self.world, g // self.world] for g in range(n_points)]
 
 
 def point_filename(config, point, a):

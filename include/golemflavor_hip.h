@@ -237,6 +237,9 @@ int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* 
 
 /* same with DEVICE destinations d_fr [nchains][nstored][nwalkers][3], d_status (NULL = skip); synchronous */
 int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double* d_fr, int32_t* d_status);
+/* the rows a scan saves, assembled on the device: d_rows [nchains][nstored][nwalkers][3 + ndim] = composition (NaN where the
+ * reference would have raised) then the sample (scripts/mc_texture.py:216-223); synchronous */
+int gf_sampler_postprocess_rows_device(gf_sampler* s, gf_model* const* models, double* d_rows);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only

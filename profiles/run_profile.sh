@@ -8,9 +8,11 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler"
+ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler --no-extras"
 # the trace pass runs bench.py's default step counts, so that its per-kernel average is the number bench.py prints
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-sampler > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-sampler --no-extras > $OUT/bench_trace.json 2> $OUT/trace.err
+# ... and one trace of the whole default command (sub-records included): every kernel of every BASELINE configuration
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 bench.py --no-cpu-baseline > $OUT/bench_trace_full.json 2> $OUT/trace_full.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
