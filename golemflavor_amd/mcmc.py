@@ -306,11 +306,10 @@ class DeviceEnsembleSampler:
 
     PEND_CAP = 16384
 
-    def _check_flags(self):
+    def _count_nonunitary(self):
         """Non-unitary proposals since the last reset.  The kernels settle the verdict of almost every proposal
         themselves (csrc/gf_bsm_device.hpp, tiers 1-2); the few they cannot were evaluated as unitary and logged, and
-        get their exact verdict here through the bulk path (x87-faithful arbitration).  Reference behaviour: the run
-        dies on the first such proposal (fr.py:493-498)."""
+        get their exact verdict here through the bulk path (x87-faithful arbitration)."""
         C = self._C
         n = (C.c_uint32 * 1)()
         self._lib.check(self._L.gf_sampler_get_chain(self._h, None, None, None, n), "gf_sampler_get_chain")
@@ -332,11 +331,20 @@ class DeviceEnsembleSampler:
                 st = model.lnprob(th)[1]
                 self._pend_bad = getattr(self, "_pend_bad", 0) + int(np.sum(st == self._lib.GF_ST_NON_UNITARY))
             self._pend_seen = cnt.value
-        bad += getattr(self, "_pend_bad", 0)
-        self.nonunitary_proposals = bad
-        if bad and self.on_nonunitary == "raise":
-            # reference: AssertionError out of test_unitarity kills the run (fr.py:493-498)
-            raise AssertionError("Matrix is not unitary! (%d proposals)" % bad)
+        return bad + getattr(self, "_pend_bad", 0)
+
+    @property
+    def nonunitary_proposals(self):
+        """How many proposals since the last reset a reference run would have died on (fr.py:493-498)."""
+        return self._count_nonunitary()
+
+    def _check_flags(self):
+        # reference behaviour: AssertionError out of test_unitarity kills the run (fr.py:493-498); with
+        # on_nonunitary="-inf" the count is only taken when somebody asks for it (`nonunitary_proposals`)
+        if self.on_nonunitary == "raise":
+            bad = self._count_nonunitary()
+            if bad:
+                raise AssertionError("Matrix is not unitary! (%d proposals)" % bad)
 
     # -- results --------------------------------------------------------------------------
     @property
