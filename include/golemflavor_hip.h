@@ -12,8 +12,10 @@
  *   - every function returns a gf_error (0 = GF_OK) and never throws; gf_strerror() explains it;
  *   - arrays are caller-owned, fp64, row-major; theta is [n][ndim] exactly as emcee hands it over;
  *   - per-walker outcomes travel in `status` (gf_status), not in the return code;
- *   - a gf_model is bound to one device and one HIP stream; calls on one model are serialised by
- *     that stream, different models may be driven from different host threads;
+ *   - a gf_model is bound to one device and one HIP stream.  Thread-safe per handle: the entry points that use the
+ *     model's staging buffers or its unitarity queue (gf_lnprob_batch, gf_propagate_batch, gf_lnprob_cube_batch, the
+ *     *_device launches) take a per-model lock, so several host threads may share one model (their calls run one
+ *     after the other); different models are independent and may be driven concurrently;
  *   - there is NO CPU fallback: without a gfx950 device gf_model_create returns GF_ERR_NO_DEVICE.
  */
 #ifndef GOLEMFLAVOR_HIP_H

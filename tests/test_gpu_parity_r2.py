@@ -301,3 +301,44 @@ def test_deferred_tier2_equals_inline(oracle):
     r80 = oracle.unitarity_residual_batch(om, th[pick])
     dec = _decided(r80)
     assert np.array_equal((st_big[pick] == _lib.GF_ST_NON_UNITARY)[dec], (r80 >= 1e-7)[dec])
+
+
+def test_two_threads_share_one_model(golden):
+    """The host-buffer entry points stage through buffers that belong to the model: two host threads hammering ONE model
+    with different batches (sizes either side of the zero-copy limit, SM and BSM) must each get their own results."""
+    import threading
+    from common import notebook_sets, uniform_theta
+    _, ps = notebook_sets(golden)
+    sm = Model(compile_model(ps, "SM_GAUSS", bestfit_fr=golden["g6_bestfit_fr"], smearing=0.02))
+    ps7 = Cf.texture_paramset(6)
+    bsm = Model(compile_model(ps7, "BSM_GAUSS", texture=Texture.OEU, dimension=6, binning=BIN_EDGES, source_ratio=(0., 1., 0.),
+                              bestfit_fr=(1 / 3,) * 3, smearing=0.02))
+    rng = np.random.default_rng(21)
+    batches = {}
+    for t in range(2):
+        a = golden["g6_theta"][t * 2000:t * 2000 + (1500 if t else 3000)]
+        b = uniform_theta(ps7, 2500 if t else 900, rng, seeds=True)
+        b[:, 6] = rng.uniform(-56, -30, len(b))
+        batches[t] = (a, b)
+    want = {t: (sm.lnprob(a, want_fr=True), bsm.lnprob(b, want_fr=True)) for t, (a, b) in batches.items()}
+    errors = []
+
+    def work(t):
+        try:
+            a, b = batches[t]
+            for _ in range(40):
+                got_a, got_b = sm.lnprob(a, want_fr=True), bsm.lnprob(b, want_fr=True)
+                for g, w in zip(got_a + got_b, want[t][0] + want[t][1]):
+                    if not np.array_equal(g, w, equal_nan=True):
+                        raise AssertionError("thread %d got another batch's numbers" % t)
+        except Exception as exc:          # noqa: BLE001
+            errors.append(exc)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    sm.close()
+    bsm.close()
+    assert not errors, errors
