@@ -96,6 +96,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
         const int64_t nend = (LPW > 1 && w0 + WPT < n) ? w0 + WPT : n;     // stage this tile's WPT rows only
         stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane, nend);
         const int64_t i = w0 + lane / LPW;
+        bool defer = false;
         if (i < n) {
             const double* row = tile + (lane / LPW) * ndim;
             double lp = 0.0;
@@ -115,10 +116,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
                     // walker counts as unitary
                     else if (acc.amb != 0 && sub == 0 && uq) queue_pairs(uq, i, acc.amb);
                 }
-                if (UNI_MODE == UNI_DEFER && acc.a_min < tb->uni_a_ok) {
-                    const unsigned int at = atomicAdd(&wq->count, 1u);          // tier 1 does not clear this walker
-                    if (at < wq->cap) wq->items[at] = (unsigned long long)i;
-                }
+                if (UNI_MODE == UNI_DEFER) defer = acc.a_min < tb->uni_a_ok;      // tier 1 does not clear this walker
                 if (WITH_LLH) {
                     // llh.py:109-112: fr -> fr_to_angles -> (Gaussian substitute) angles_to_fr is the
                     // identity on a normalised composition up to rounding
@@ -133,6 +131,20 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
                 if (WITH_LLH) lnprob[i] = val;
                 if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
                 if (status) status[i] = st;
+            }
+        }
+        if (UNI_MODE == UNI_DEFER) {
+            // one atomic per wave, not per walker: the lanes that queue their walker take consecutive slots
+            const unsigned long long m = __ballot(defer);
+            if (m != 0) {
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned int base = 0;
+                if (lane == leader) base = atomicAdd(&wq->count, (unsigned int)__popcll(m));
+                base = (unsigned int)__shfl((int)base, leader);
+                if (defer) {
+                    const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (at < wq->cap) wq->items[at] = (unsigned long long)i;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

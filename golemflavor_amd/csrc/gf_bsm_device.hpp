@@ -177,7 +177,6 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
     const double a = al * s, t = be * s;
-    if (UNI_MODE == UNI_DEFER) acc.a_min = fmin(acc.a_min, a);
     if (UNI_MODE == UNI_ONLY && !(a < tb->uni_a_ok)) return;          // tier 1 clears this bin: nothing to evaluate
     const double aa = a * a, at = a * t, tt = t * t;
     const double b = fma(aa, w.bS, fma(at, w.bSN, tt * w.bN));
@@ -301,6 +300,8 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     Herm3 Sn, Nn;
     BinInv w;
     bin_invariants(S, N, Sn, Nn, w);
+    // the smallest SM weight over the bins, a_k = 1 / (1 + (v_k / u_k) trN / trS), from the largest v_k / u_k of the table
+    if (UNI_MODE == UNI_DEFER) acc.a_min = fast_rcp(fma(tb->rho_max, w.trN * fast_rcp(w.trS), 1.0));
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
     // src / sum(src) (fr.py:535): the E^gamma factor cancels, so the spectral index has no effect.
     const double isrc = fast_rcp(c.src_fixed_sum);

@@ -488,6 +488,8 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
             b.weight[k] = std::fabs(d->bin_edges[k + 1] - d->bin_edges[k]);        // fr.py:414
             b.inv2e[k] = 1.0 / (2 * e);                                            // fr.py:386
             b.epow[k] = std::pow(e, (double)(d->dimension - 3));                   // fr.py:394
+            const double rho = b.epow[k] / b.inv2e[k];
+            if (k == 0 || rho > b.rho_max) b.rho_max = rho;
         }
         if (d->texture != GF_TEX_NONE) {
             const double z = 0. + 1e-9;                                            // fr.py:370
@@ -526,6 +528,7 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
             b.uni_hi = 1e-7 * 2048.0 * std::pow(10.0, hi_dec);
             b.uni_lo_nl = 1e-7 * 2048.0 * std::pow(10.0, -lo_nl_dec);
             if (std::getenv("GF_UNI_NO_WEIGHT_GATE")) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
+            if (const char* e = std::getenv("GF_UNI_A_OK")) b.uni_a_ok = std::atof(e);  // diagnostics: tier 1's threshold
             if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = b.uni_lo_nl = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the estimate
         }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order

@@ -68,6 +68,7 @@ struct GfBsm {
     double uni_a_ok, uni_a_lin;
     double uni_lo, uni_hi;          // a >= uni_a_lin
     double uni_lo_nl;               // a <  uni_a_lin: the estimate acquits only far below the threshold and never condemns
+    double rho_max;                 // max_k epow[k] / inv2e[k]: the smallest SM weight over the bins is 1 / (1 + rho_max trN / trS)
 };
 
 // Work queue of the unitarity arbitration: (walker, energy bin) pairs whose fp64 estimate of the reference's
