@@ -282,7 +282,7 @@ static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const
 // followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq,
-                         int cus, hipStream_t s)
+                         unsigned int* seen, int cus, hipStream_t s)
 {
     if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
@@ -294,7 +294,7 @@ hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBs
                                    lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, wq, cus, s);
         if (e != hipSuccess) return e;
         e = gf_launch_uni_resolve(d_common, d_bsm, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, c.ndim,
-                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, m * nbins, cus, s);
+                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, m * nbins, seen, cus, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

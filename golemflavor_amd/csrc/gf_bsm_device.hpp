@@ -70,7 +70,14 @@ __device__ __forceinline__ Herm3 rank2(double w1, const double ar[3], const doub
 // Columns 1 and 2 of the mixing matrix for (s12^2, c13^4, s23^2, delta): fr.py:116-162, SURVEY A.2.
 // Once (twice for texture NONE) per walker against 20 bin diagonalisations: kept out of line so that its
 // literals and temporaries do not inflate the bin loop's register allocation.
-static __device__ __attribute__((noinline)) void mixing_cols12(double s12_2, double c13_4, double s23_2, double dcp,
+// Inlined since round 2 (+5-7 % on the bulk kernel, and no call frame: scratch 0); -DGF_MIX_NOINLINE restores the out-of-line
+// call of round 1 (A/B in profiles/r02/ab_bsm_variants.txt)
+#ifndef GF_MIX_NOINLINE
+#define GF_MIX_ATTR __forceinline__
+#else
+#define GF_MIX_ATTR __attribute__((noinline))
+#endif
+static __device__ GF_MIX_ATTR void mixing_cols12(double s12_2, double c13_4, double s23_2, double dcp,
                                               double c1r[3], double c1i[3], double c2r[3], double c2i[3])
 {
     const double c13_2 = fast_sqrt(c13_4);
@@ -183,8 +190,25 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
     const double det = at * fma(a, w.m1, t * w.m2);
     const double Q = fma(-3.0, b, 1.0) * (1.0 / 9.0);                 // (a^2 - 3b)/9 with a = -tr = -1
     const double R = (fma(9.0, b, -2.0) - 27.0 * det) * (1.0 / 54.0); // (2a^3 - 9ab + 27c)/54, c = -det
+#ifndef GF_NO_RSQ_CUBE          // 1 / Q^(3/2) from the square root's own reciprocal instead of a second division (+1 %, A/B as above)
+    double sq, x;
+    {
+        const double y = __builtin_amdgcn_rsq(Q);
+        double g = Q * y, h = 0.5 * y;
+        const double r0 = fma(-h, g, 0.5);
+        g = fma(g, r0, g);
+        h = fma(h, r0, h);
+        const double d = fma(-g, g, Q);
+        g = fma(d, h, g);
+        h = fma(fma(-h, g, 0.5), h, h);                    // 1 / (2 sqrt Q), refined once more
+        sq = Q == 0.0 ? 0.0 : g;
+        const double ih = h + h;                          // 1 / sqrt Q
+        x = R * ((ih * ih) * ih);
+    }
+#else
     const double sq = fast_sqrt(Q);
     double x = R * fast_rcp(Q * sq);
+#endif
     x = fmin(1.0, fmax(-1.0, x));
     const double phi = fast_acos(x) * (1.0 / 3.0);
     double sp, cp;
@@ -308,6 +332,9 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     const double s0 = c.src_fixed[0] * isrc, s1 = c.src_fixed[1] * isrc, s2 = c.src_fixed[2] * isrc;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int nb = tb->nbins;
+#ifdef GF_BIN_UNROLL1
+#pragma unroll 1
+#endif
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];

@@ -126,6 +126,7 @@ struct gf_model {
     // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
     GfUniQueue* d_uq = nullptr;
     GfUniQueue* d_wq = nullptr;  // walkers for the deferred tier 2 (same lifetime as d_uq; capacity uq_cap / nbins)
+    unsigned int* h_seen = nullptr;   // pinned: items the last arbitration launch found (gf_launch_uni_resolve sizes its grid by it)
     int64_t uq_cap = 0;
     GfUniQueue h_uq_hdr = {0, 0, 0, 0, {0}};
     std::mutex call_mu;          // serialises the entry points that use the model's staging buffers / queue
@@ -265,6 +266,10 @@ int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
     }
     int64_t cap = m->uq_cap ? m->uq_cap : 4096;
     while (cap < need) cap *= 2;
+    if (!m->h_seen) {
+        GF_HIP(hipHostMalloc((void**)&m->h_seen, 64, hipHostMallocDefault));
+        *m->h_seen = 0;
+    }
     GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
     if (m->d_uq) (void)hipFree(m->d_uq);
     if (m->d_wq) (void)hipFree(m->d_wq);
@@ -290,7 +295,7 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->h_seen, m->cus, st);
     }
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
@@ -305,7 +310,7 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->h_seen, m->cus, st);
     }
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
@@ -600,6 +605,7 @@ void gf_model_destroy(gf_model* m)
     if (m->d_cube) (void)hipFree(m->d_cube);
     if (m->d_uq) (void)hipFree(m->d_uq);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->h_seen) (void)hipHostFree(m->h_seen);
     delete m;
 }
 

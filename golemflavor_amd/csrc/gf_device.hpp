@@ -198,7 +198,11 @@ __device__ __forceinline__ double fast_acos(double x)
 }
 
 // 10^x for the NP scale (fr.py:380 np.power(10., logLam)); once per walker, out of line.
+#ifdef GF_POW_INLINE            // A/B switch (tools/build_variants.sh)
+static __device__ __forceinline__ double pow10_cold(double x) { return pow(10.0, x); }
+#else
 static __device__ __attribute__((noinline)) double pow10_cold(double x) { return pow(10.0, x); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Stage one wave's 64 x ndim block of theta into its LDS tile (row-major [64][ndim]).

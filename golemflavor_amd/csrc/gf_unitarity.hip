@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "gf_consts.h"
 #include "gf_launch.h"
 #include "gf_x87.hpp"
@@ -71,7 +73,7 @@ __device__ __attribute__((noinline)) double pair_residual(const GfCommon& c, con
 __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                            const double* __restrict__ theta, int layout, int64_t n,
                                                            double* __restrict__ lnprob, int32_t* __restrict__ status,
-                                                           GfUniQueue* __restrict__ uq)
+                                                           GfUniQueue* __restrict__ uq, unsigned int* __restrict__ seen)
 {
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
     const unsigned int stride = gridDim.x * UNI_BLOCK;
@@ -94,20 +96,35 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
             uq->count = 0;
             uq->done = 0;
             __threadfence();
+            // what this launch found, in host memory: sizes the grid of the next one (gf_launch_uni_resolve)
+            if (seen) { __atomic_store_n(seen, count, __ATOMIC_RELAXED); __threadfence_system(); }
         }
     }
 }
 
 }  // namespace
 
+// The grid.  pair_residual keeps its 3x3 complex matrices in scratch (~2 KB per lane): a grid that fills the GPU asks the
+// runtime for ~0.5 GB of scratch, more than a queue retains, so that EVERY launch would pay an allocation (~30 us
+// measured on an empty queue, profiles/r02) -- as much as the evaluation of 130 000 walkers.  The queue is empty or
+// nearly so wherever the posterior lives, so the grid follows what the previous launch on this model found (`seen`, a
+// word of pinned host memory the kernel's last block writes; read here without synchronisation, stale is fine: any
+// grid is correct, the kernel strides): a few blocks while the queue stays short, the whole GPU in the failing region.
 hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int ndim,
-                                 double* lnprob, int32_t* status, GfUniQueue* uq, int64_t max_items, int cus, hipStream_t s)
+                                 double* lnprob, int32_t* status, GfUniQueue* uq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s)
 {
     (void)ndim;
-    int64_t blocks = (max_items + UNI_BLOCK - 1) / UNI_BLOCK;
+    int64_t expect = max_items;
+    if (seen) {
+        const int64_t last = (int64_t)__atomic_load_n(seen, __ATOMIC_RELAXED);
+        expect = 2 * last < max_items ? 2 * last : max_items;
+    }
+    int64_t blocks = (expect + UNI_BLOCK - 1) / UNI_BLOCK;
     const int64_t cap = (int64_t)cus * 8;
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq);
+    if (blocks < 32) blocks = 32;
+    static const int forced = [] { const char* e = std::getenv("GF_UNI_RESOLVE_BLOCKS"); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
+    if (forced > 0) blocks = forced;
+    hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, seen);
     return hipGetLastError();
 }
