@@ -61,7 +61,8 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
+                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq,
+                                                      double* __restrict__ t2sn)
 {
     constexpr bool CHECK_UNI = UNI_MODE == UNI_INLINE;
     // the constants by pointer (the model's device block), not by value: as a 848-B kernel argument the compiler loads
@@ -89,6 +90,9 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
     const int sub = LPW > 1 ? lane % LPW : 0;
     double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * GF_FGRP_DOUBLES(tb->nbins, LPW) : nullptr;
     double* tile = tiles[wave];
+    // UNI_DEFER: walkers waiting to be queued for k_bsm_tier2, per wave (a tile adds at most 64 to fewer than 64)
+    __shared__ int64_t pend[UNI_MODE == UNI_DEFER ? GF_WAVES_PER_BLOCK : 1][UNI_MODE == UNI_DEFER ? 2 * GF_WAVE : 1];
+    int npend = 0;
     const int64_t ntiles = (n + WPT - 1) / WPT;
     const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
             int st = ST_OUT_OF_PRIOR;
             if (inbox) {
                 UniAcc acc = {0.0, 0.0, 0ull, 2.0};
-                flux_average<UNI_MODE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
+                flux_average<UNI_MODE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp, UNI_MODE == UNI_DEFER ? t2sn + i * GF_SN_DOUBLES : nullptr);
                 st = ST_OK;
                 if (CHECK_UNI) {
                     if (tb->uni_lo < 0.0) fr[0] = acc.est_max * (1.0 / UNI_EST_SCALE);  // diagnostics (GF_UNI_DUMP): the estimate itself
@@ -134,54 +138,68 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
             }
         }
         if (UNI_MODE == UNI_DEFER) {
-            // one atomic per wave, not per walker: the lanes that queue their walker take consecutive slots
+            // The walkers to queue collect in the wave's LDS list and leave for the global queue 64 or more at a time:
+            // one atomic per ~64 queued walkers.  (One per wave and tile -- 65 536 returning atomics on one address for
+            // 4 M walkers -- cost the evaluation kernel 18 %, profiles/r02/bsm_defer_atomics.txt.)
             const unsigned long long m = __ballot(defer);
             if (m != 0) {
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned int base = 0;
-                if (lane == leader) base = atomicAdd(&wq->count, (unsigned int)__popcll(m));
-                base = (unsigned int)__shfl((int)base, leader);
-                if (defer) {
-                    const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-                    if (at < wq->cap) wq->items[at] = (unsigned long long)i;
+                if (defer) pend[wave][npend + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                npend += __popcll(m);                                    // wave-uniform
+                if (npend >= GF_WAVE) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(&wq->count, (unsigned int)npend);
+                    base = (unsigned int)__shfl((int)base, 0);
+                    for (int j = lane; j < npend; j += GF_WAVE)
+                        if (base + j < wq->cap) wq->items[base + j] = (unsigned long long)pend[wave][j];
+                    npend = 0;
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (UNI_MODE == UNI_DEFER) {
+        // what is left in the four lists goes out with one atomic per block
+        __shared__ unsigned int blk_off[GF_WAVES_PER_BLOCK + 1];
+        __shared__ unsigned int blk_base;
+        if (lane == 0) blk_off[wave + 1] = (unsigned int)npend;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            blk_off[0] = 0;
+            for (int w = 0; w < GF_WAVES_PER_BLOCK; ++w) { tot += blk_off[w + 1]; blk_off[w + 1] = tot; }
+            blk_base = tot ? atomicAdd(&wq->count, tot) : 0u;
+        }
+        __syncthreads();
+        const unsigned int base = blk_base + blk_off[wave];
+        for (int j = lane; j < npend; j += GF_WAVE)
+            if (base + j < wq->cap) wq->items[base + j] = (unsigned long long)pend[wave][j];
+    }
 }
 
 // Tier 2 for the walkers the evaluation kernel queued (UNI_DEFER): the fp64 estimate of the bins tier 1 does not clear,
 // one lane per walker, full waves of them -- instead of every wave of the evaluation running tier 2 because one of its
-// 64 walkers needs it.  Same classification as the inline path: condemned walkers get NON_UNITARY (and a NaN value),
-// undecided (walker, bin) pairs go on to the arbitration queue.
-__global__ __launch_bounds__(GF_BLOCK, 2) void k_bsm_tier2(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
-                                                           const double* __restrict__ theta, int layout, int64_t n,
-                                                           double* __restrict__ lnprob, int32_t* __restrict__ status,
-                                                           GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
+// 64 walkers needs it.  The walker's Hamiltonian terms come from `t2sn` (left there by the evaluation kernel), so there
+// is no prologue to repeat.  Same classification as the inline path: condemned walkers get NON_UNITARY (and a NaN
+// value), undecided (walker, bin) pairs go on to the arbitration queue.
+#ifndef GF_T2_WAVES
+#define GF_T2_WAVES 2
+#endif
+__global__ __launch_bounds__(GF_BLOCK, GF_T2_WAVES) void k_bsm_tier2(const GfBsm* __restrict__ tb, const double* __restrict__ t2sn, int64_t n,
+                                                                     double* __restrict__ lnprob, int32_t* __restrict__ status,
+                                                                     GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
 {
-    const GfCommon& c = *cp;
-    __shared__ __attribute__((aligned(16))) double rows[GF_BLOCK][GF_MAX_DIM];
-    __shared__ __attribute__((aligned(16))) double ttab[20];
-    if (threadIdx.x < 18) {
-        const int k = threadIdx.x, e = k >> 1;
-        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
-        const bool im = e == 4 || e == 6 || e == 8;
-        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
-        ttab[k] = srcp[idx];
-    }
-    __syncthreads();
-    const int ndim = c.ndim;
     const unsigned int count = wq->count < wq->cap ? wq->count : wq->cap;
-    double* row = rows[threadIdx.x];
     for (unsigned int q = blockIdx.x * GF_BLOCK + threadIdx.x; q < count; q += gridDim.x * GF_BLOCK) {
         const int64_t i = (int64_t)wq->items[q];
         if (i >= n) continue;
-        for (int d = 0; d < ndim; ++d) row[d] = layout == 0 ? theta[i * ndim + d] : theta[(int64_t)d * n + i];
+        Herm3 S, N;
+        load_sn(t2sn + i * GF_SN_DOUBLES, S, N);
         UniAcc acc = {0.0, 0.0, 0ull, 2.0};
-        double fr[3];
-        flux_average<UNI_ONLY, 1>(c, tb, ttab, row, fr, acc);
+        tier2_from_sn(tb, S, N, acc);
         if (!(acc.clear_max < tb->uni_hi)) {
             status[i] = ST_NON_UNITARY;
             if (lnprob) lnprob[i] = gf_nan();
@@ -189,16 +207,8 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_bsm_tier2(const GfCommon* __res
             queue_pairs(uq, i, acc.amb);
         }
     }
-    // the last block to finish re-arms the walker queue for the next launch on this stream
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&wq->done, 1u) == gridDim.x - 1) {
-            wq->count = 0;
-            wq->done = 0;
-            __threadfence();
-        }
-    }
+    // the walker queue is re-armed by k_uni_resolve, which follows in stream order (one store there instead of a fence
+    // and an atomic per block here)
 }
 
 inline int grid_for(int64_t work_items, int per_block, int cus)
@@ -230,20 +240,20 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 
 template <int NDIM, int LPW>
 hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int cus, hipStream_t s)
+                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
 {
     const int grid = grid_for(n * LPW, GF_BLOCK, cus);
     const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * GF_FGRP_DOUBLES(nbins, LPW) * sizeof(double) : 0;
     // status requested: tiers 1-2 inline (wq == NULL) or deferred to k_bsm_tier2 (large batches, one lane per walker)
     const int mode = status == nullptr ? UNI_NONE : (wq != nullptr && LPW == 1 ? UNI_DEFER : UNI_INLINE);
-#define GF_GO(WL, UM) hipLaunchKernelGGL((k_bsm<NDIM, WL, UM, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status, uq, wq)
+#define GF_GO(WL, UM) hipLaunchKernelGGL((k_bsm<NDIM, WL, UM, LPW>), dim3(grid), dim3(GF_BLOCK), lds, s, d_common, d_bsm, ptab, theta, layout, n, lnprob, fr, status, uq, wq, t2sn)
     if (with_llh) { if (mode == UNI_NONE) GF_GO(true, UNI_NONE); else if (mode == UNI_INLINE) GF_GO(true, UNI_INLINE); else { if constexpr (LPW == 1) GF_GO(true, UNI_DEFER); } }
     else          { if (mode == UNI_NONE) GF_GO(false, UNI_NONE); else if (mode == UNI_INLINE) GF_GO(false, UNI_INLINE); else { if constexpr (LPW == 1) GF_GO(false, UNI_DEFER); } }
 #undef GF_GO
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && mode == UNI_DEFER) {
         const int g2 = grid_for(n / 4 + 1, GF_BLOCK, cus);
-        hipLaunchKernelGGL(k_bsm_tier2, dim3(g2), dim3(GF_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, with_llh ? lnprob : nullptr, status, uq, wq);
+        hipLaunchKernelGGL(k_bsm_tier2, dim3(g2), dim3(GF_BLOCK), 0, s, d_bsm, t2sn, n, with_llh ? lnprob : nullptr, status, uq, wq);
         e = hipGetLastError();
     }
     return e;
@@ -251,12 +261,12 @@ hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d
 
 template <int NDIM>
 hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
-                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int cus, hipStream_t s)
+                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
 {
     switch (lanes_for(n, nbins, cus, status != nullptr)) {
-    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, cus, s);
-    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, cus, s);
-    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
+    case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, nullptr, cus, s);
+    case 16: return launch_nl<NDIM, 16>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, nullptr, cus, s);
+    default: return launch_nl<NDIM, 1>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, t2sn, cus, s);
     }
 }
 
@@ -267,34 +277,34 @@ hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_
 // the walker index in the queue.
 static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta,
                               int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq,
-                              int cus, hipStream_t s)
+                              double* t2sn, int cus, hipStream_t s)
 {
     switch (c.ndim) {
-    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
-    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
-    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, cus, s);
+    case 7: return launch_n<7>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, t2sn, cus, s);
+    case 12: return launch_n<12>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, t2sn, cus, s);
+    default: return launch_n<0>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, wq, t2sn, cus, s);
     }
 }
 
 // `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested; `wq`: its queue of
-// walkers for k_bsm_tier2 (capacity >= uq_cap / nbins walkers), NULL = tiers inline.  With a status array
+// walkers for k_bsm_tier2 (capacity >= uq_cap / nbins walkers) and `t2sn` their Hamiltonian terms ([capacity][18]), NULL = tiers inline.  With a status array
 // an AoS batch is cut into pieces whose worst case (every bin of every walker undecided) fits the queue, each piece
 // followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
                          int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq,
-                         unsigned int* seen, int cus, hipStream_t s)
+                         double* t2sn, unsigned int* seen, int cus, hipStream_t s)
 {
-    if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, cus, s);
+    if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
     if (piece < 1) piece = 1;
     if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n
     for (int64_t w0 = 0; w0 < n; w0 += piece) {
         const int64_t m = n - w0 < piece ? n - w0 : piece;
         hipError_t e = launch_eval(c, d_common, d_bsm, nbins, ptab, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, with_llh,
-                                   lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, wq, cus, s);
+                                   lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, wq, t2sn, cus, s);
         if (e != hipSuccess) return e;
         e = gf_launch_uni_resolve(d_common, d_bsm, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, c.ndim,
-                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, m * nbins, seen, cus, s);
+                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, wq, m * nbins, seen, cus, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

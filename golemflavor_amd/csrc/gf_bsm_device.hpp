@@ -285,6 +285,42 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
     }
 }
 
+// The two terms of a walker's Hamiltonian as the evaluation kernel leaves them for k_bsm_tier2: [S (9) | N (9)]
+constexpr int GF_SN_DOUBLES = 18;
+__device__ __forceinline__ void store_sn(const Herm3& S, const Herm3& N, double* __restrict__ o)
+{
+    double2* o2 = reinterpret_cast<double2*>(o);                      // rows are 16-B aligned (18 doubles = 144 B)
+    o2[0] = make_double2(S.d0, S.d1);   o2[1] = make_double2(S.d2, S.r01);  o2[2] = make_double2(S.i01, S.r02);
+    o2[3] = make_double2(S.i02, S.r12); o2[4] = make_double2(S.i12, N.d0);  o2[5] = make_double2(N.d1, N.d2);
+    o2[6] = make_double2(N.r01, N.i01); o2[7] = make_double2(N.r02, N.i02); o2[8] = make_double2(N.r12, N.i12);
+}
+__device__ __forceinline__ void load_sn(const double* __restrict__ o, Herm3& S, Herm3& N)
+{
+    const double2* o2 = reinterpret_cast<const double2*>(o);
+    const double2 q0 = o2[0], q1 = o2[1], q2 = o2[2], q3 = o2[3], q4 = o2[4], q5 = o2[5], q6 = o2[6], q7 = o2[7], q8 = o2[8];
+    S.d0 = q0.x; S.d1 = q0.y; S.d2 = q1.x; S.r01 = q1.y; S.i01 = q2.x; S.r02 = q2.y; S.i02 = q3.x; S.r12 = q3.y; S.i12 = q4.x;
+    N.d0 = q4.y; N.d1 = q5.x; N.d2 = q5.y; N.r01 = q6.x; N.i01 = q6.y; N.r02 = q7.x; N.i02 = q7.y; N.r12 = q8.x; N.i12 = q8.y;
+}
+
+// Tiers 1-2 of one walker from its stored Hamiltonian terms (k_bsm_tier2): the same bin_invariants / bin_moduli calls,
+// hence the same estimates bit for bit, as flux_average<UNI_INLINE> makes.
+__device__ __forceinline__ void tier2_from_sn(const GfBsm* __restrict__ tb, const Herm3& S, const Herm3& N, UniAcc& acc)
+{
+    Herm3 Sn, Nn;
+    BinInv w;
+    bin_invariants(S, N, Sn, Nn, w);
+    // a = al / (al + be) clearly at or above uni_a_ok <=> be < skip_be al: tier 1 clears the bin (bin_moduli decides
+    // the borderline itself)
+    const double skip_be = (1.0 - tb->uni_a_ok) * fast_rcp(tb->uni_a_ok) * (1.0 - 1e-9);
+    const int nb = tb->nbins;
+    for (int k = 0; k < nb; ++k) {
+        const double u = tb->inv2e[k], v = tb->epow[k];
+        if (v * w.trN < skip_be * (u * w.trS)) continue;
+        double p[3][3];
+        bin_moduli<UNI_ONLY>(w, Sn, Nn, u, v, p, acc, k, tb);
+    }
+}
+
 // flux_averaged_BSMu for one walker (fr.py:403-458).  Returns the normalised composition and the worst
 // unitarity residual over the bins.
 //
@@ -296,7 +332,7 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
 template <int UNI_MODE, int LPW = 1>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
                                              const double* row, double fr[3], UniAcc& acc, int sub = 0,
-                                             double* fgrp = nullptr)
+                                             double* fgrp = nullptr, double* sn_out = nullptr)
 {
     // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
     double c1r[3], c1i[3], c2r[3], c2i[3];
@@ -325,7 +361,12 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     BinInv w;
     bin_invariants(S, N, Sn, Nn, w);
     // the smallest SM weight over the bins, a_k = 1 / (1 + (v_k / u_k) trN / trS), from the largest v_k / u_k of the table
-    if (UNI_MODE == UNI_DEFER) acc.a_min = fast_rcp(fma(tb->rho_max, w.trN * fast_rcp(w.trS), 1.0));
+    if (UNI_MODE == UNI_DEFER) {
+        acc.a_min = fast_rcp(fma(tb->rho_max, w.trN * fast_rcp(w.trS), 1.0));
+        // tier 1 does not clear this walker: leave its two Hamiltonian terms for k_bsm_tier2 (18 doubles; the stores
+        // retire behind the bin loop), which then needs neither theta nor the per-walker prologue
+        if (sn_out && acc.a_min < tb->uni_a_ok) store_sn(S, N, sn_out);
+    }
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
     // src / sum(src) (fr.py:535): the E^gamma factor cancels, so the spectral index has no effect.
     const double isrc = fast_rcp(c.src_fixed_sum);
@@ -339,7 +380,6 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
         bin_moduli<UNI_MODE>(w, Sn, Nn, u, v, p, acc, k, tb);
-        if (UNI_MODE == UNI_ONLY) continue;                             // the verdict only: no composition
         // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
         const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
         const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));

@@ -126,6 +126,7 @@ struct gf_model {
     // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
     GfUniQueue* d_uq = nullptr;
     GfUniQueue* d_wq = nullptr;  // walkers for the deferred tier 2 (same lifetime as d_uq; capacity uq_cap / nbins)
+    double* d_t2sn = nullptr;    // [capacity of d_wq][18]: Hamiltonian terms of the queued walkers (gf_bsm.hip)
     unsigned int* h_seen = nullptr;   // pinned: items the last arbitration launch found (gf_launch_uni_resolve sizes its grid by it)
     int64_t uq_cap = 0;
     GfUniQueue h_uq_hdr = {0, 0, 0, 0, {0}};
@@ -259,7 +260,11 @@ int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
     const int64_t nb = m->hb.nbins > 0 ? m->hb.nbins : 1;
     int64_t need = n * nb;
     if (layout == GF_LAYOUT_AOS && need > UQ_MAX_ITEMS) need = UQ_MAX_ITEMS > nb ? UQ_MAX_ITEMS : nb;
-    if (need <= m->uq_cap) return GF_OK;
+    if (need <= m->uq_cap) {
+        // the first large batch on a queue that small batches sized: the deferred tier 2 needs its side buffer
+        if (n >= GF_TIER2_SPLIT_MIN && !m->d_t2sn) GF_HIP(hipMalloc((void**)&m->d_t2sn, sizeof(double) * 18 * (size_t)(m->uq_cap / nb + 1)));
+        return GF_OK;
+    }
     if (need > 0xffffffffLL) {
         std::snprintf(g_err, sizeof(g_err), "a structure-of-arrays batch of %lld walkers with a status array exceeds the arbitration queue", (long long)n);
         return GF_ERR_UNSUPPORTED;
@@ -273,10 +278,12 @@ int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
     GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
     if (m->d_uq) (void)hipFree(m->d_uq);
     if (m->d_wq) (void)hipFree(m->d_wq);
-    m->d_uq = nullptr; m->d_wq = nullptr; m->uq_cap = 0;
+    if (m->d_t2sn) (void)hipFree(m->d_t2sn);
+    m->d_uq = nullptr; m->d_wq = nullptr; m->d_t2sn = nullptr; m->uq_cap = 0;
     const int64_t wcap = cap / nb + 1;
     GF_HIP(hipMalloc((void**)&m->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
     GF_HIP(hipMalloc((void**)&m->d_wq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)wcap));
+    if (n >= GF_TIER2_SPLIT_MIN) GF_HIP(hipMalloc((void**)&m->d_t2sn, sizeof(double) * 18 * (size_t)wcap));
     m->h_uq_hdr.count = 0; m->h_uq_hdr.done = 0; m->h_uq_hdr.cap = (unsigned int)cap; m->h_uq_hdr.pad_ = 0;
     GF_HIP(hipMemcpyAsync(m->d_uq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
     GF_HIP(hipStreamSynchronize(st));
@@ -295,7 +302,7 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->h_seen, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN && m->d_t2sn ? m->d_wq : nullptr, m->d_t2sn, m->h_seen, m->cus, st);
     }
     else
         e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
@@ -310,7 +317,7 @@ int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int lay
     if (m->c.mode == GF_MODE_BSM_GAUSS) {
         if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN ? m->d_wq : nullptr, m->h_seen, m->cus, st);
+                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN && m->d_t2sn ? m->d_wq : nullptr, m->d_t2sn, m->h_seen, m->cus, st);
     }
     else
         e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
@@ -605,6 +612,7 @@ void gf_model_destroy(gf_model* m)
     if (m->d_cube) (void)hipFree(m->d_cube);
     if (m->d_uq) (void)hipFree(m->d_uq);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_t2sn) (void)hipFree(m->d_t2sn);
     if (m->h_seen) (void)hipHostFree(m->h_seen);
     delete m;
 }

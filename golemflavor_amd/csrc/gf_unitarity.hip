@@ -73,7 +73,7 @@ __device__ __attribute__((noinline)) double pair_residual(const GfCommon& c, con
 __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                            const double* __restrict__ theta, int layout, int64_t n,
                                                            double* __restrict__ lnprob, int32_t* __restrict__ status,
-                                                           GfUniQueue* __restrict__ uq, unsigned int* __restrict__ seen)
+                                                           GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq, unsigned int* __restrict__ seen)
 {
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
     const unsigned int stride = gridDim.x * UNI_BLOCK;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
         if (atomicAdd(&uq->done, 1u) == gridDim.x - 1) {
             uq->count = 0;
             uq->done = 0;
+            if (wq) wq->count = 0;                                      // k_bsm_tier2's walker queue: it ran before this kernel
             __threadfence();
             // what this launch found, in host memory: sizes the grid of the next one (gf_launch_uni_resolve)
             if (seen) { __atomic_store_n(seen, count, __ATOMIC_RELAXED); __threadfence_system(); }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
 // word of pinned host memory the kernel's last block writes; read here without synchronisation, stale is fine: any
 // grid is correct, the kernel strides): a few blocks while the queue stays short, the whole GPU in the failing region.
 hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int ndim,
-                                 double* lnprob, int32_t* status, GfUniQueue* uq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s)
+                                 double* lnprob, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s)
 {
     (void)ndim;
     int64_t expect = max_items;
@@ -125,6 +126,6 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
     if (blocks < 32) blocks = 32;
     static const int forced = [] { const char* e = std::getenv("GF_UNI_RESOLVE_BLOCKS"); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
     if (forced > 0) blocks = forced;
-    hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, seen);
+    hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);
     return hipGetLastError();
 }
