@@ -38,9 +38,19 @@
 namespace {
 using namespace gfdev;
 
-#ifndef GF_BSM_WAVES
-#define GF_BSM_WAVES 2
+// waves per SIMD the evaluation kernel is compiled for, by unitarity mode: without the estimate in the loop body the kernel
+// needs ~155 VGPRs (three waves fit in the 512-entry file), with tiers 1-2 inline ~210 (two)
+#ifndef GF_BSM_WAVES_NONE
+#define GF_BSM_WAVES_NONE 3
 #endif
+#ifndef GF_BSM_WAVES_DEFER
+#define GF_BSM_WAVES_DEFER 3
+#endif
+#ifndef GF_BSM_WAVES_INLINE
+#define GF_BSM_WAVES_INLINE 2
+#endif
+// (the generic-width instances, NDIM = 0, index the row at run time and need ~180: two waves)
+#define GF_BSM_WAVES(UM, ND) ((ND) == 0 ? 2 : (UM) == UNI_NONE ? GF_BSM_WAVES_NONE : (UM) == UNI_DEFER ? GF_BSM_WAVES_DEFER : GF_BSM_WAVES_INLINE)
 // LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
 // SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
 // walkers per tile.  Results are bitwise those of LPW = 1.
@@ -57,7 +67,7 @@ __device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t
 // UNI_MODE (gf_bsm_device.hpp): UNI_NONE no status; UNI_INLINE tiers 1-2 inside the evaluation (small batches);
 // UNI_DEFER the evaluation only notes the walkers tier 1 does not clear (`wq`) and k_bsm_tier2 runs tier 2 on those.
 template <int NDIM, bool WITH_LLH, int UNI_MODE, int LPW>
-__global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
+__global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
@@ -105,7 +115,15 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES) void k_bsm(const GfCommon* 
             const double* row = tile + (lane / LPW) * ndim;
             double lp = 0.0;
             bool inbox = true;
-            if (WITH_LLH) inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
+            if (WITH_LLH) {
+                inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
+#ifndef GF_PRIOR_SINK
+                // pin the prior sum here: `lp` is next needed after the bin loop, and left alone the compiler sinks its
+                // arithmetic there, carrying x, loc and 1/sigma of every column through the loop (72 VGPRs at 12 columns:
+                // 225 instead of 153, the difference between two and three waves per SIMD)
+                asm volatile("" : "+v"(lp));
+#endif
+            }
             double fr[3] = {gf_nan(), gf_nan(), gf_nan()};
             double val = -gf_inf();
             int st = ST_OUT_OF_PRIOR;

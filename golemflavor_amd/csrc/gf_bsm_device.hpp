@@ -180,7 +180,7 @@ template <int UNI_MODE>
 __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
                                            double p[3][3], UniAcc& acc, int kbin, const GfBsm* __restrict__ tb)
 {
-    constexpr bool CHECK_UNI = UNI_MODE == UNI_INLINE || UNI_MODE == UNI_ONLY;
+    constexpr bool CHECK_UNI = UNI_MODE == UNI_ONLY;                 // the values and the estimate never share a loop body
     const double al = u * w.trS, be = v * w.trN;
     const double s = fast_rcp(al + be);
     const double a = al * s, t = be * s;
@@ -302,22 +302,59 @@ __device__ __forceinline__ void load_sn(const double* __restrict__ o, Herm3& S, 
     N.d0 = q4.y; N.d1 = q5.x; N.d2 = q5.y; N.r01 = q6.x; N.i01 = q6.y; N.r02 = q7.x; N.i02 = q7.y; N.r12 = q8.x; N.i12 = q8.y;
 }
 
-// Tiers 1-2 of one walker from its stored Hamiltonian terms (k_bsm_tier2): the same bin_invariants / bin_moduli calls,
-// hence the same estimates bit for bit, as flux_average<UNI_INLINE> makes.
+// Tiers 1-2 of one walker from its normalised Hamiltonian terms: k_bsm_tier2 (terms stored by the evaluation kernel) and
+// flux_average<UNI_INLINE> (ahead of its value loop) run this same code on the same bin_invariants output, hence produce
+// the same estimates bit for bit.  Keeping the estimate out of the value loop's body is what keeps the evaluation kernels
+// free of scratch: the two loops need their registers one after the other, not together.  `sub`, `lpw`: this lane takes
+// the bins sub, sub + lpw, ...
+__device__ __forceinline__ void tier2_bins(const GfBsm* __restrict__ tb, const BinInv& w, const Herm3& Sn, const Herm3& Nn, UniAcc& acc,
+                                           int sub = 0, int lpw = 1)
+{
+    // a = al / (al + be) clearly at or above uni_a_ok <=> be < skip_be al: tier 1 clears the bin (bin_moduli decides
+    // the borderline itself)
+    const double skip_be = (1.0 - tb->uni_a_ok) * fast_rcp(tb->uni_a_ok) * (1.0 - 1e-9);
+    const int nb = tb->nbins;
+    for (int k = sub; k < nb; k += lpw) {
+        const double u = tb->inv2e[k], v = tb->epow[k];
+        if (v * w.trN < skip_be * (u * w.trS)) continue;
+        double p[3][3];
+        bin_moduli<UNI_ONLY>(w, Sn, Nn, u, v, p, acc, k, tb);
+    }
+}
 __device__ __forceinline__ void tier2_from_sn(const GfBsm* __restrict__ tb, const Herm3& S, const Herm3& N, UniAcc& acc)
 {
     Herm3 Sn, Nn;
     BinInv w;
     bin_invariants(S, N, Sn, Nn, w);
-    // a = al / (al + be) clearly at or above uni_a_ok <=> be < skip_be al: tier 1 clears the bin (bin_moduli decides
-    // the borderline itself)
-    const double skip_be = (1.0 - tb->uni_a_ok) * fast_rcp(tb->uni_a_ok) * (1.0 - 1e-9);
-    const int nb = tb->nbins;
-    for (int k = 0; k < nb; ++k) {
-        const double u = tb->inv2e[k], v = tb->epow[k];
-        if (v * w.trN < skip_be * (u * w.trS)) continue;
-        double p[3][3];
-        bin_moduli<UNI_ONLY>(w, Sn, Nn, u, v, p, acc, k, tb);
+    tier2_bins(tb, w, Sn, Nn, acc);
+}
+
+// The two terms of a walker's Hamiltonian before the energy factors: S = U diag(0, m21, m3x) U^+ (fr.py:383-386) and
+// N = U~ diag(0, sc1, sc2) U~^+ (fr.py:380-393).
+__device__ __forceinline__ void hamiltonian_terms(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
+                                                  const double* row, Herm3& S, Herm3& N)
+{
+    // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
+    double c1r[3], c1i[3], c2r[3], c2i[3];
+    mixing_cols12(pick(row, c.idx_sm[0], c.sm_fixed[0]), pick(row, c.idx_sm[1], c.sm_fixed[1]),
+                  pick(row, c.idx_sm[2], c.sm_fixed[2]), pick(row, c.idx_sm[3], c.sm_fixed[3]), c1r, c1i, c2r, c2i);
+    S = rank2(pick(row, c.idx_mass[0], c.mass_fixed[0]), c1r, c1i,
+                          pick(row, c.idx_mass[1], c.mass_fixed[1]), c2r, c2i);
+    // NP part, per walker: sc1 T1 + sc2 T2, sc2 = 10^logLam, sc1 = sc2/100   (fr.py:380-393)
+    const double sc2 = pow10_cold(pick(row, c.idx_scale, c.scale_fixed));
+    const double sc1 = sc2 / 100.0;
+    if (tb->texture == TEX_NONE) {
+        mixing_cols12(pick(row, c.idx_mm[0], c.mm_fixed[0]), pick(row, c.idx_mm[1], c.mm_fixed[1]),
+                      pick(row, c.idx_mm[2], c.mm_fixed[2]), pick(row, c.idx_mm[3], c.mm_fixed[3]), c1r, c1i, c2r, c2i);
+        N = rank2(sc1, c1r, c1i, sc2, c2r, c2i);
+    } else {
+        // ttab (LDS): the 18 entries of T1, T2 that a Hermitian 3x3 needs, laid out {t1, t2} pairs
+        N.d0 = fma(sc1, ttab[0], sc2 * ttab[1]);
+        N.d1 = fma(sc1, ttab[2], sc2 * ttab[3]);
+        N.d2 = fma(sc1, ttab[4], sc2 * ttab[5]);
+        N.r01 = fma(sc1, ttab[6], sc2 * ttab[7]);   N.i01 = fma(sc1, ttab[8], sc2 * ttab[9]);
+        N.r02 = fma(sc1, ttab[10], sc2 * ttab[11]); N.i02 = fma(sc1, ttab[12], sc2 * ttab[13]);
+        N.r12 = fma(sc1, ttab[14], sc2 * ttab[15]); N.i12 = fma(sc1, ttab[16], sc2 * ttab[17]);
     }
 }
 
@@ -334,39 +371,21 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
                                              const double* row, double fr[3], UniAcc& acc, int sub = 0,
                                              double* fgrp = nullptr, double* sn_out = nullptr)
 {
-    // SM part, per walker: U diag(0, m21, m3x) U^+ = m21 u1 u1^+ + m3x u2 u2^+   (fr.py:383-386)
-    double c1r[3], c1i[3], c2r[3], c2i[3];
-    mixing_cols12(pick(row, c.idx_sm[0], c.sm_fixed[0]), pick(row, c.idx_sm[1], c.sm_fixed[1]),
-                  pick(row, c.idx_sm[2], c.sm_fixed[2]), pick(row, c.idx_sm[3], c.sm_fixed[3]), c1r, c1i, c2r, c2i);
-    const Herm3 S = rank2(pick(row, c.idx_mass[0], c.mass_fixed[0]), c1r, c1i,
-                          pick(row, c.idx_mass[1], c.mass_fixed[1]), c2r, c2i);
-    // NP part, per walker: sc1 T1 + sc2 T2, sc2 = 10^logLam, sc1 = sc2/100   (fr.py:380-393)
-    const double sc2 = pow10_cold(pick(row, c.idx_scale, c.scale_fixed));
-    const double sc1 = sc2 / 100.0;
-    Herm3 N;
-    if (tb->texture == TEX_NONE) {
-        mixing_cols12(pick(row, c.idx_mm[0], c.mm_fixed[0]), pick(row, c.idx_mm[1], c.mm_fixed[1]),
-                      pick(row, c.idx_mm[2], c.mm_fixed[2]), pick(row, c.idx_mm[3], c.mm_fixed[3]), c1r, c1i, c2r, c2i);
-        N = rank2(sc1, c1r, c1i, sc2, c2r, c2i);
-    } else {
-        // ttab (LDS): the 18 entries of T1, T2 that a Hermitian 3x3 needs, laid out {t1, t2} pairs
-        N.d0 = fma(sc1, ttab[0], sc2 * ttab[1]);
-        N.d1 = fma(sc1, ttab[2], sc2 * ttab[3]);
-        N.d2 = fma(sc1, ttab[4], sc2 * ttab[5]);
-        N.r01 = fma(sc1, ttab[6], sc2 * ttab[7]);   N.i01 = fma(sc1, ttab[8], sc2 * ttab[9]);
-        N.r02 = fma(sc1, ttab[10], sc2 * ttab[11]); N.i02 = fma(sc1, ttab[12], sc2 * ttab[13]);
-        N.r12 = fma(sc1, ttab[14], sc2 * ttab[15]); N.i12 = fma(sc1, ttab[16], sc2 * ttab[17]);
+    Herm3 S, N;
+    hamiltonian_terms(c, tb, ttab, row, S, N);
+    // the smallest SM weight over the bins, a_k = 1 / (1 + (v_k / u_k) trN / trS), from the largest v_k / u_k of the table
+    // (the traces as bin_invariants forms them)
+    if (UNI_MODE == UNI_DEFER || UNI_MODE == UNI_INLINE) {
+        const double trS = (S.d0 + S.d1) + S.d2, trN = (N.d0 + N.d1) + N.d2;
+        acc.a_min = fast_rcp(fma(tb->rho_max, trN * fast_rcp(trS), 1.0));
+        // tier 1 does not clear this walker: leave its two Hamiltonian terms for k_bsm_tier2 (18 doubles; the stores
+        // retire behind the bin loop), which then needs neither theta nor the per-walker prologue.  Ahead of
+        // bin_invariants: S and N die there, and the kernel's register peak is there too.
+        if (sn_out && acc.a_min < tb->uni_a_ok) store_sn(S, N, sn_out);
     }
     Herm3 Sn, Nn;
     BinInv w;
     bin_invariants(S, N, Sn, Nn, w);
-    // the smallest SM weight over the bins, a_k = 1 / (1 + (v_k / u_k) trN / trS), from the largest v_k / u_k of the table
-    if (UNI_MODE == UNI_DEFER) {
-        acc.a_min = fast_rcp(fma(tb->rho_max, w.trN * fast_rcp(w.trS), 1.0));
-        // tier 1 does not clear this walker: leave its two Hamiltonian terms for k_bsm_tier2 (18 doubles; the stores
-        // retire behind the bin loop), which then needs neither theta nor the per-walker prologue
-        if (sn_out && acc.a_min < tb->uni_a_ok) store_sn(S, N, sn_out);
-    }
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
     // src / sum(src) (fr.py:535): the E^gamma factor cancels, so the spectral index has no effect.
     const double isrc = fast_rcp(c.src_fixed_sum);
@@ -393,6 +412,21 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
             const double wk = tb->weight[k];
             a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1); a2 = fma(f2, wk, a2);   // fr.py:454
         }
+    }
+    // UNI_INLINE, second phase: tier 2 for the walkers tier 1 does not clear (none where the posterior lives).  The terms
+    // are rebuilt from the row rather than kept: 36 registers live across the value loop would spill (the row offset goes
+    // through an empty asm so that the compiler does not merge the two evaluations and keep them after all).  Tried and
+    // worse: tier 2 ahead of the value loop (more spills), and as a noinline call (the callee saves ~200 registers).
+    if (UNI_MODE == UNI_INLINE && __builtin_expect(acc.a_min < tb->uni_a_ok, 0)) {
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const double* row2 = row + opaque;
+        Herm3 S2, N2;
+        hamiltonian_terms(c, tb, ttab, row2, S2, N2);
+        Herm3 Sn2, Nn2;
+        BinInv w2;
+        bin_invariants(S2, N2, Sn2, Nn2, w2);
+        tier2_bins(tb, w2, Sn2, Nn2, acc, LPW > 1 ? sub : 0, LPW);
     }
     if (LPW > 1) {
         if (UNI_MODE == UNI_INLINE) {

@@ -273,7 +273,7 @@ int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
     while (cap < need) cap *= 2;
     if (!m->h_seen) {
         GF_HIP(hipHostMalloc((void**)&m->h_seen, 64, hipHostMallocDefault));
-        *m->h_seen = 0;
+        *m->h_seen = 0xffffffffu;                // nothing seen yet: the first launch takes the full grid
     }
     GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
     if (m->d_uq) (void)hipFree(m->d_uq);

@@ -106,6 +106,7 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
     if (MODE == MODE_BSM_GAUSS) {
         double lp;
         const bool inbox = lnprior_tab<NDIM>(ctab, row, ndim, c.prior_const, lp);
+        asm volatile("" : "+v"(lp));       // keeps the prior sum ahead of the bin loop (see k_bsm, gf_bsm.hip)
         val = -gf_inf();
         st = ST_OUT_OF_PRIOR;
         if (inbox) {
@@ -307,8 +308,11 @@ struct PersistArgs {
     const uint64_t* stream_ids;     // as StretchArgs::stream_ids
 };
 
-template <int NDIM, int MODE>
-__global__ __launch_bounds__(1024) void k_stretch_persist(const PersistArgs s)
+// MAXT: the largest workgroup the instance is compiled for.  1024 threads cap the kernel at 128 VGPRs, which the canonical
+// posterior overflows by a few (32-256 B of scratch per lane inside the step loop); ensembles of up to 512 walkers (the
+// reference's 100-walker chain runs on ONE wave) take the 256-thread instance, which has the registers it wants.
+template <int NDIM, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
 {
     constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -405,10 +409,13 @@ inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds)
 template <int NDIM>
 hipError_t launch_persist_n(int mode, int nchains, int threads, size_t lds, const PersistArgs& a, hipStream_t st)
 {
-    if (mode == MODE_PRIOR_ONLY)
-        hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY>), dim3(nchains), dim3(threads), lds, st, a);
-    else
-        hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS>), dim3(nchains), dim3(threads), lds, st, a);
+    if (mode == MODE_PRIOR_ONLY) {
+        if (threads <= 256) hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY, 256>), dim3(nchains), dim3(threads), lds, st, a);
+        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY, 1024>), dim3(nchains), dim3(threads), lds, st, a);
+    } else {
+        if (threads <= 256) hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS, 256>), dim3(nchains), dim3(threads), lds, st, a);
+        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS, 1024>), dim3(nchains), dim3(threads), lds, st, a);
+    }
     return hipGetLastError();
 }
 

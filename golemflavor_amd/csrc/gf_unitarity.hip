@@ -110,20 +110,25 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
 // measured on an empty queue, profiles/r02) -- as much as the evaluation of 130 000 walkers.  The queue is empty or
 // nearly so wherever the posterior lives, so the grid follows what the previous launch on this model found (`seen`, a
 // word of pinned host memory the kernel's last block writes; read here without synchronisation, stale is fine: any
-// grid is correct, the kernel strides): a few blocks while the queue stays short, the whole GPU in the failing region.
+// grid is correct, the kernel strides): a fraction of the GPU while the queue stays short, the whole GPU in the failing region.
 hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int ndim,
                                  double* lnprob, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s)
 {
     (void)ndim;
     int64_t expect = max_items;
     if (seen) {
-        const int64_t last = (int64_t)__atomic_load_n(seen, __ATOMIC_RELAXED);
+        const int64_t last = (int64_t)__atomic_load_n(seen, __ATOMIC_RELAXED);     // 0xffffffff: nothing seen yet
         expect = 2 * last < max_items ? 2 * last : max_items;
     }
     int64_t blocks = (expect + UNI_BLOCK - 1) / UNI_BLOCK;
     const int64_t cap = (int64_t)cus * 8;
     if (blocks > cap) blocks = cap;
-    if (blocks < 32) blocks = 32;
+    // A floor under the grid: a queue that fills up unannounced -- the first batch of a scan that enters the failing region --
+    // is worked off by whatever grid the hint gave.  Launch cost grows with the grid even where the queue keeps the scratch
+    // (an empty queue: ~5 us up to 128 blocks, 8 at 256, 13 at 512, 35 at 2048), so small batches, where those microseconds
+    // are the call, get 64 blocks, and batches whose evaluation takes longer than that anyway one block per CU.
+    const int64_t floor_blocks = max_items >= 65536 * 16 ? cus : 64;
+    if (blocks < floor_blocks) blocks = floor_blocks;
     static const int forced = [] { const char* e = std::getenv("GF_UNI_RESOLVE_BLOCKS"); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
     if (forced > 0) blocks = forced;
     hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);

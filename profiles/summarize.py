@@ -71,6 +71,14 @@ big = defaultdict(lambda: defaultdict(list))
 for r in rows("pmc_sq/**/*counter_collection.csv"):
     if "k_bsm<" in r["Kernel_Name"] and r["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
         big[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# effective clock of those dispatches: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / wall time of the same dispatch
+# (MI355X_MICROARCH.md, "DVFS give-back": the chip lowers its clock under load)
+clk = defaultdict(list)
+for r in rows("pmc_sq2/**/*counter_collection.csv"):
+    if "k_bsm<" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE" and int(r["Grid_Size"]) == 524288:
+        ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if ns > 0:
+            clk[r["Kernel_Name"]].append(float(r["Counter_Value"]) / 8.0 / ns)          # cycles per ns = GHz
 instr = {}
 N_BIG = 4 * 1024 * 1024
 for (k, grid), cs in big.items():
@@ -86,7 +94,11 @@ for (k, grid), cs in big.items():
     if m.group(3) == "0":
         instr[key] = {"kernel": k[:70], "valu_wave_instr_per_launch": valu, "walkers_per_launch": N_BIG,
                       "valu_wave_instr_per_walker": valu / (N_BIG / 64.0), "valu_instr_per_bin_incl_prologue": valu / (N_BIG / 64.0) / 20.0}
+        if clk.get(k):
+            v = sorted(clk[k])
+            instr[key]["effective_clock_ghz"] = v[len(v) // 2]
 if instr:
-    instr["note"] = "rocprofv3 --pmc SQ_INSTS_VALU, tools/bench_bsm.py, dispatches of 4 194 304 walkers (grid 524288), 20 energy bins"
+    instr["note"] = ("rocprofv3 --pmc SQ_INSTS_VALU, tools/bench_bsm.py, dispatches of 4 194 304 walkers (grid 524288), 20 energy bins; "
+                     "effective_clock_ghz = GRBM_GUI_ACTIVE / 8 / dispatch wall time (median over the dispatches)")
     json.dump(instr, open(os.path.join(out, "bsm_instr.json"), "w"), indent=1)
     print("bsm_instr:", json.dumps(instr))
