@@ -52,6 +52,7 @@ from golemflavor_amd.model import Model  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_EVAL = 6 * 8 + 8     # 8*ndim read + 8 written, no fr / status blob
 SCLK_PEAK_GHZ = 2.4
+SETTLE_MS = 100.0                         # untimed steps before the warm-up, see main()
 FP64_ISSUE_PER_S = 256 * 4 * SCLK_PEAK_GHZ * 1e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one fp64 VALU instruction per 4 cycles at 2.4 GHz
 
 
@@ -131,9 +132,17 @@ def _claim_stdout():
 
 # ---------------------------------------------------------------------------------------------------------------
 # sub-records: the other BASELINE configurations, device-resident, HIP-event timed, each a few seconds at most
-def _timed(model, fn, reps, warm=2):
+def _timed(model, fn, reps, warm=2, warm_ms=60.0):
+    """Average HIP-event time of `reps` back-to-back calls, after `warm` calls and at least `warm_ms` of them: from idle
+    the chip needs tens of milliseconds under load to reach the clock it then holds (a 14 ms burst of the BSM kernel straight
+    after a pause reads 10-15 % slow)."""
     for _ in range(warm):
         fn()
+    t0 = time.perf_counter()
+    while warm_ms > 0 and (time.perf_counter() - t0) * 1e3 < warm_ms:
+        for _ in range(4):
+            fn()
+        model.sync()
     e0, e1 = model.event(), model.event()
     model.sync()
     e0.record()
@@ -187,8 +196,8 @@ def extra_bulk(device, ps, label, n=4 * 1024 * 1024):
     with Model(desc, device=device) as m:
         d_th = m.alloc(th.nbytes).upload(th)
         d_out, d_st = m.alloc(8 * n), m.alloc(4 * n)
-        # the chip's clock under this kernel wanders by several per cent from one burst of launches to the next (power
-        # management): the two modes are timed in alternation, three bursts of 20 launches each, and the median is kept
+        # the two modes in alternation, three bursts of 20 launches each (every burst behind _timed's warm-up); the median is
+        # kept and the bursts are listed
         bursts = {"no_status": [], "with_status": []}
         for _ in range(3):
             for key, st in (("no_status", None), ("with_status", d_st.ptr)):
@@ -204,13 +213,6 @@ def extra_bulk(device, ps, label, n=4 * 1024 * 1024):
                 # wave-instructions retired per second over what 1024 SIMDs can issue (one fp64 instruction per 4 cycles)
                 rec["valu_instr_per_walker"] = ipw
                 rec["fp64_issue_fraction"] = (n / 64.0) * ipw / (ms * 1e-3) / FP64_ISSUE_PER_S
-                # the chip holds ~2.1 GHz under this kernel, not the 2.4 GHz the peak is quoted at (GRBM_GUI_ACTIVE / 8 /
-                # wall time of the profiled dispatches, MI355X_MICROARCH.md "DVFS give-back"): the same count against
-                # the issue slots that actually existed
-                ghz = (consts or {}).get("%d_%s" % (len(ps), key), {}).get("effective_clock_ghz")
-                if ghz:
-                    rec["effective_clock_ghz_profiled"] = ghz
-                    rec["fp64_issue_fraction_at_held_clock"] = rec["fp64_issue_fraction"] * (SCLK_PEAK_GHZ / ghz)
             out[key] = rec
         # where the unitarity verdict is not free: logLam over the FULL range of a texture that fails at its top (OEU)
         th[:, -1] = rng.uniform(lo, hi, n)
@@ -220,7 +222,7 @@ def extra_bulk(device, ps, label, n=4 * 1024 * 1024):
         n2 = n // 4
         d_th = m.alloc(th[:n2].nbytes).upload(th[:n2])
         d_out, d_st = m.alloc(8 * n2), m.alloc(4 * n2)
-        ms = _timed(m, lambda: m.lnprob_device(d_th.ptr, n2, d_out.ptr, None, d_st.ptr), reps=3, warm=1)
+        ms = _timed(m, lambda: m.lnprob_device(d_th.ptr, n2, d_out.ptr, None, d_st.ptr), reps=3, warm=1, warm_ms=0)
         st = d_st.download((n2,), dtype=np.int32)
         out["with_status_through_the_failing_region"] = {
             "workload": "texture OEU, logLam over its whole range (the top fails the reference's unitarity assert): every "
@@ -283,10 +285,17 @@ def extra_emcee(model, ps, walkers):
         p1 = rngp.uniform(box[:, 0], box[:, 1], size=(nch, 100, 6))
         smp = mcmc_utils.DeviceEnsembleSampler(100, 6, model, nchains=nch, seed=26)
         smp.run_mcmc(p1 if nch > 1 else p1[0], 100, storechain=False)
+        e0, e1 = model.event(), model.event()
         t0 = time.perf_counter()
-        smp.run_mcmc(None, steps, storechain=False)
+        e0.record()
+        smp.run_async(None, steps, storechain=False)      # the run: enqueue ...
+        e1.record()
+        smp.wait()                                        # ... and wait for it (what run_mcmc does, less the state read-back)
         dt = time.perf_counter() - t0
+        smp.state                                         # positions + lnprob back on the host, once per run
+        dt_state = time.perf_counter() - t0 - dt
         rows.append({"chains": nch, "steps": steps, "us_per_step": 1e6 * dt / steps, "evals_per_s": 100.0 * nch * steps / dt,
+                     "kernel_us_per_step": 1e3 * e0.elapsed_ms(e1) / steps, "state_readback_ms": 1e3 * dt_state,
                      "acceptance_fraction": float(np.mean(smp.acceptance_fraction))})
         smp.close()
     l1 = rows[0]["us_per_step"]
@@ -339,6 +348,13 @@ def main():
         control.barrier()
         model.sync()
 
+    # settle the clock: from idle the chip needs tens of milliseconds under load to reach the state it then holds, and a
+    # short run (--steps 20 is 3.5 ms) would otherwise be timed inside that ramp.  Untimed, ahead of the W warm-up steps.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < SETTLE_MS:
+        for _ in range(16):
+            step()
+        model.sync()
     for _ in range(a.warmup):
         step()
     ev0, ev1 = model.event(), model.event()
@@ -394,7 +410,8 @@ def main():
             pass
         out = {
             "metric": metric, "value": value, "unit": "evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_ms_before_warmup": SETTLE_MS,
+            "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: examples/inference.ipynb 6-dim Gaussian-llh posterior, %d-walker ensembles, "
                                    "%d independent ensembles stacked per launch per GPU (theta resident in HBM)"

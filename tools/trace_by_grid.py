@@ -17,7 +17,7 @@ def short(name):
 def main(path):
     if os.path.isdir(path):
         files = glob.glob(os.path.join(path, "**", "*_kernel_trace.csv"), recursive=True)
-        path = max(files, key=os.path.getsize)
+        path = max(files, key=os.path.getmtime)          # a merged gpurun_out/ keeps older runs: the newest
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         agg[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]), r.get("Scratch_Size", "?"), r.get("VGPR_Count", "?"))].append(
