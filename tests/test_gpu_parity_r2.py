@@ -303,6 +303,59 @@ def test_deferred_tier2_equals_inline(oracle):
     assert np.array_equal((st_big[pick] == _lib.GF_ST_NON_UNITARY)[dec], (r80 >= 1e-7)[dec])
 
 
+def test_deferred_queue_flushes_inside_the_kernel():
+    """The evaluation kernel collects the walkers tier 1 does not clear in per-wave LDS lists and queues them 64 or more at a
+    time; what is left goes out per block at the end.  600 000 walkers, all of them in the high-scale region (every wave
+    fills its list several times over, the last tile is ragged): status and values must be those of the inline path on the
+    same rows, bit for bit."""
+    from common import uniform_theta
+    dim, tex = 6, Texture.OEU
+    ps = Cf.texture_paramset(dim)
+    lo, hi = Cf.SCALE_BOUNDARIES[dim]
+    rng = np.random.default_rng(7)
+    n = 600_007
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[:, -1] = rng.uniform(hi - 7.0, hi, n)
+    kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(0., 1., 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    with Model(compile_model(ps, "BSM_GAUSS", texture=tex, **kw)) as m:
+        lp_big, st_big = m.lnprob(th)                                             # one call: deferred
+        parts = [m.lnprob(th[i:i + 60000]) for i in range(0, n, 60000)]           # eleven calls: inline
+    lp = np.concatenate([p[0] for p in parts]); st = np.concatenate([p[1] for p in parts])
+    assert np.array_equal(st_big, st)
+    assert np.array_equal(lp_big, lp, equal_nan=True)
+    assert 0.3 < np.mean(st == _lib.GF_ST_NON_UNITARY) < 0.99
+
+
+def test_status_does_not_depend_on_what_the_model_ran_before():
+    """The arbitration grid follows the queue length the previous launch found, the deferred tier 2's side buffer is allocated
+    by the first large batch, and both queues are re-armed on the device: none of that history may show in the results.
+    A batch through the failing region gives the same status and values on a fresh model and on one that has just run a
+    small batch (tiers inline, queue sized small) and a large low-scale batch (empty queues, smallest grid)."""
+    from common import uniform_theta
+    dim, tex = 6, Texture.OEU
+    _, ps = Cf.fr_paramsets(dim, (0.4, 0.0))
+    lo, hi = Cf.SCALE_BOUNDARIES[dim]
+    rng = np.random.default_rng(5)
+    n = 90_001
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[:, -1] = rng.uniform(lo, hi, n)
+    low = th.copy()
+    low[:, -1] = rng.uniform(lo, lo + 6.0, n)
+    kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(1 / 3, 2 / 3, 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    desc = compile_model(ps, "BSM_GAUSS", texture=tex, **kw)
+    with Model(desc) as fresh:
+        want = fresh.lnprob(th, want_fr=True)
+    with Model(desc) as m:
+        m.lnprob(th[:900])
+        _, st_low = m.lnprob(low)
+        assert (st_low == _lib.GF_ST_OK).all()
+        got = m.lnprob(th, want_fr=True)
+        again = m.lnprob(th, want_fr=True)
+    for a, b, c in zip(want, got, again):
+        assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+    assert 0.1 < np.mean(want[2] == _lib.GF_ST_NON_UNITARY) < 0.3
+
+
 def test_two_threads_share_one_model(golden):
     """The host-buffer entry points stage through buffers that belong to the model: two host threads hammering ONE model
     with different batches (sizes either side of the zero-copy limit, SM and BSM) must each get their own results."""
