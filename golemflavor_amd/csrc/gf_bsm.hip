@@ -305,15 +305,16 @@ static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const
 }
 
 // `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested; `wq`: its queue of
-// walkers for k_bsm_tier2 (capacity >= uq_cap / nbins walkers) and `t2sn` their Hamiltonian terms ([capacity][18]), NULL = tiers inline.  With a status array
+// walkers for k_bsm_tier2 (`wq_cap` walkers) and `t2sn` their Hamiltonian terms ([wq_cap][18]), NULL = tiers inline.  With a status array
 // an AoS batch is cut into pieces whose worst case (every bin of every walker undecided) fits the queue, each piece
 // followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
                          double* t2sn, unsigned int* seen, int cus, hipStream_t s)
 {
     if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
+    if (wq && wq_cap < piece) piece = wq_cap;                            // ... and the walker queue of the deferred tier 2
     if (piece < 1) piece = 1;
     if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n
     for (int64_t w0 = 0; w0 < n; w0 += piece) {

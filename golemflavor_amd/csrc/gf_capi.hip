@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/golemflavor_hip.h"
@@ -124,12 +125,6 @@ struct gf_model {
     double* d_cube = nullptr;    // gf_lnprob_cube_batch: the unit-cube rows on the device
     size_t cube_cap = 0;
     // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
-    GfUniQueue* d_uq = nullptr;
-    GfUniQueue* d_wq = nullptr;  // walkers for the deferred tier 2 (same lifetime as d_uq; capacity uq_cap / nbins)
-    double* d_t2sn = nullptr;    // [capacity of d_wq][18]: Hamiltonian terms of the queued walkers (gf_bsm.hip)
-    unsigned int* h_seen = nullptr;   // pinned: items the last arbitration launch found (gf_launch_uni_resolve sizes its grid by it)
-    int64_t uq_cap = 0;
-    GfUniQueue h_uq_hdr = {0, 0, 0, 0, {0}};
     std::mutex call_mu;          // serialises the entry points that use the model's staging buffers / queue
 };
 
@@ -142,16 +137,46 @@ namespace {
 constexpr int64_t GF_ZEROCOPY_MAX_ROWS = 2048;
 constexpr int POOL_MAX_DEVICES = 64;
 constexpr size_t POOL_MAX_ITEMS = 1024;
+constexpr size_t WORK_CACHE_MAX_BYTES = (size_t)8 << 30;     // idle unitarity workspaces kept per device (of 288 GB)
 constexpr size_t CONST_PTAB_BYTES = sizeof(double) * GF_MAX_DIM * 4;
 constexpr size_t CONST_BSM_OFFSET = (CONST_PTAB_BYTES + 255) / 256 * 256;
 constexpr size_t CONST_COMMON_OFFSET = (CONST_BSM_OFFSET + sizeof(GfBsm) + 255) / 256 * 256;
 constexpr size_t CONST_BLOCK_BYTES = CONST_COMMON_OFFSET + sizeof(GfCommon);
+
+// What the unitarity verdict of a batch needs besides the caller's arrays (gf_bsm.hip, gf_unitarity.hip): the arbitration
+// queue, the walker queue and side buffer of the deferred tier 2, and one pinned word through which the arbitration kernel
+// tells the host how long its queue was.  It belongs to the STREAM, not to the model: launches on one stream run in order,
+// so every model that launches there can use the same workspace -- the 64 per-grid-point models of a texture scan, which
+// propagate their chains one after the other on the sampler's stream, share one instead of allocating (and, worse,
+// freeing: hipFree ~0.25 ms and a device synchronisation each) three buffers apiece -- and it stays with the stream when
+// the stream goes back to the pool.
+struct UniWork {
+    std::mutex mu;                 // held from sizing the workspace to the last launch that uses it
+    GfUniQueue* d_uq = nullptr;    // [uq_cap] (walker, bin) pairs
+    GfUniQueue* d_wq = nullptr;    // [wq_cap] walkers
+    double* d_t2sn = nullptr;      // [wq_cap][18]
+    unsigned int* h_seen = nullptr;
+    int64_t uq_cap = 0, wq_cap = 0;
+    size_t bytes() const
+    {
+        return (d_uq ? sizeof(unsigned long long) * (size_t)uq_cap : 0) + (d_wq ? sizeof(unsigned long long) * (size_t)wq_cap : 0) +
+               (d_t2sn ? sizeof(double) * 18 * (size_t)wq_cap : 0);
+    }
+    void release()
+    {
+        if (d_uq) (void)hipFree(d_uq);
+        if (d_wq) (void)hipFree(d_wq);
+        if (d_t2sn) (void)hipFree(d_t2sn);
+        d_uq = d_wq = nullptr; d_t2sn = nullptr; uq_cap = wq_cap = 0;
+    }
+};
 
 struct DevicePool {
     int state = 0;                 // 0 unknown, 1 gfx950, -1 something else
     int cus = 256;
     std::vector<hipStream_t> streams;
     std::vector<void*> blocks;
+    std::unordered_map<hipStream_t, UniWork*> work;      // never erased while the stream lives
 };
 std::mutex g_pool_mu;
 DevicePool g_pool[POOL_MAX_DEVICES];
@@ -205,15 +230,42 @@ hipError_t pool_block(int device, void** block)
     return *block ? hipSuccess : hipMalloc(block, CONST_BLOCK_BYTES);
 }
 
+UniWork* work_for(int device, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    UniWork*& w = g_pool[device].work[stream];
+    if (!w) w = new (std::nothrow) UniWork();
+    return w;
+}
+
 // the stream must be idle (the caller synchronised it)
 void pool_release(int device, hipStream_t stream, void* block)
 {
+    UniWork* drop = nullptr;
+    bool trim = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         DevicePool& dp = g_pool[device];
+        if (stream) {
+            // the stream's workspace goes back to the pool with it, unless the idle workspaces of this device already hold
+            // WORK_CACHE_MAX_BYTES: then its buffers are released (the small bookkeeping object stays)
+            auto it = dp.work.find(stream);
+            if (it != dp.work.end() && it->second) {
+                size_t total = 0;
+                for (auto& kv : dp.work) if (kv.second) total += kv.second->bytes();
+                if (dp.streams.size() >= POOL_MAX_ITEMS) { drop = it->second; dp.work.erase(it); }
+                else if (total > WORK_CACHE_MAX_BYTES) { drop = it->second; trim = true; }
+            }
+        }
         if (stream && dp.streams.size() < POOL_MAX_ITEMS) { dp.streams.push_back(stream); stream = nullptr; }
         if (block && dp.blocks.size() < POOL_MAX_ITEMS) { dp.blocks.push_back(block); block = nullptr; }
     }
+    if (drop) {
+        std::lock_guard<std::mutex> lk(drop->mu);
+        drop->release();
+        if (!trim) { if (drop->h_seen) (void)hipHostFree(drop->h_seen); }
+    }
+    if (drop && !trim) delete drop;
     if (stream) (void)hipStreamDestroy(stream);
     if (block) (void)hipFree(block);
 }
@@ -254,43 +306,77 @@ constexpr int64_t UQ_MAX_ITEMS = 1 << 27;      // 1 GiB of items at most: ~6.7 M
                                                // when a status array is asked for on a batch that large; 288 GB of HBM)
 // from this batch size on (one lane per walker in the evaluation kernel) tier 2 runs as its own compact kernel
 constexpr int64_t GF_TIER2_SPLIT_MIN = 65536;
+constexpr int64_t WQ_MAX_WALKERS = 1 << 23;    // per piece: 8.4 M walkers, 1.2 GB of side buffer
 
-int ensure_uq(gf_model* m, hipStream_t st, int layout, int64_t n)
+int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n)
 {
-    const int64_t nb = m->hb.nbins > 0 ? m->hb.nbins : 1;
+    const int64_t nb = nbins > 0 ? nbins : 1;
     int64_t need = n * nb;
     if (layout == GF_LAYOUT_AOS && need > UQ_MAX_ITEMS) need = UQ_MAX_ITEMS > nb ? UQ_MAX_ITEMS : nb;
-    if (need <= m->uq_cap) {
-        // the first large batch on a queue that small batches sized: the deferred tier 2 needs its side buffer
-        if (n >= GF_TIER2_SPLIT_MIN && !m->d_t2sn) GF_HIP(hipMalloc((void**)&m->d_t2sn, sizeof(double) * 18 * (size_t)(m->uq_cap / nb + 1)));
-        return GF_OK;
-    }
     if (need > 0xffffffffLL) {
         std::snprintf(g_err, sizeof(g_err), "a structure-of-arrays batch of %lld walkers with a status array exceeds the arbitration queue", (long long)n);
         return GF_ERR_UNSUPPORTED;
     }
-    int64_t cap = m->uq_cap ? m->uq_cap : 4096;
-    while (cap < need) cap *= 2;
-    if (!m->h_seen) {
-        GF_HIP(hipHostMalloc((void**)&m->h_seen, 64, hipHostMallocDefault));
-        *m->h_seen = 0xffffffffu;                // nothing seen yet: the first launch takes the full grid
+    if (!w->h_seen) {
+        GF_HIP(hipHostMalloc((void**)&w->h_seen, 64, hipHostMallocDefault));
+        w->h_seen[0] = 0xffffffffu;              // nothing seen yet: the first launch takes the full grid
+        w->h_seen[1] = 0;                        // host-only flag: full grids on request (gf_internal_full_arbitration_grids)
     }
-    GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old queue
-    if (m->d_uq) (void)hipFree(m->d_uq);
-    if (m->d_wq) (void)hipFree(m->d_wq);
-    if (m->d_t2sn) (void)hipFree(m->d_t2sn);
-    m->d_uq = nullptr; m->d_wq = nullptr; m->d_t2sn = nullptr; m->uq_cap = 0;
-    const int64_t wcap = cap / nb + 1;
-    GF_HIP(hipMalloc((void**)&m->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
-    GF_HIP(hipMalloc((void**)&m->d_wq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)wcap));
-    if (n >= GF_TIER2_SPLIT_MIN) GF_HIP(hipMalloc((void**)&m->d_t2sn, sizeof(double) * 18 * (size_t)wcap));
-    m->h_uq_hdr.count = 0; m->h_uq_hdr.done = 0; m->h_uq_hdr.cap = (unsigned int)cap; m->h_uq_hdr.pad_ = 0;
-    GF_HIP(hipMemcpyAsync(m->d_uq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
-    GF_HIP(hipStreamSynchronize(st));
-    m->h_uq_hdr.cap = (unsigned int)wcap;
-    GF_HIP(hipMemcpyAsync(m->d_wq, &m->h_uq_hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
-    GF_HIP(hipStreamSynchronize(st));
-    m->uq_cap = cap;
+    int64_t cap = w->uq_cap ? w->uq_cap : 4096;
+    while (cap < need) cap *= 2;
+    // the walker queue (and the side buffer, 144 B per walker) of the deferred tier 2: one piece of the batch -- gf_launch_bsm
+    // cuts an AoS batch into pieces that fit both queues
+    const bool defer = n >= GF_TIER2_SPLIT_MIN;
+    int64_t need_w = defer ? n : 0;
+    if (layout == GF_LAYOUT_AOS && need_w > WQ_MAX_WALKERS) need_w = WQ_MAX_WALKERS;
+    if (need_w > w->wq_cap) {                 // grow at least geometrically
+        const int64_t twice = 2 * w->wq_cap < WQ_MAX_WALKERS ? 2 * w->wq_cap : WQ_MAX_WALKERS;
+        if (layout == GF_LAYOUT_AOS && twice > need_w) need_w = twice;
+    }
+    if (cap == w->uq_cap && need_w <= w->wq_cap) return GF_OK;
+    GF_HIP(hipStreamSynchronize(st));          // earlier launches may still use the old buffers
+    GfUniQueue hdr = {0, 0, 0, 0, {0}};
+    if (cap != w->uq_cap) {
+        if (w->d_uq) (void)hipFree(w->d_uq);
+        w->d_uq = nullptr; w->uq_cap = 0;
+        GF_HIP(hipMalloc((void**)&w->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
+        hdr.cap = (unsigned int)cap;
+        GF_HIP(hipMemcpyAsync(w->d_uq, &hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
+        GF_HIP(hipStreamSynchronize(st));
+        w->uq_cap = cap;
+    }
+    if (need_w > w->wq_cap) {
+        if (w->d_wq) (void)hipFree(w->d_wq);
+        if (w->d_t2sn) (void)hipFree(w->d_t2sn);
+        w->d_wq = nullptr; w->d_t2sn = nullptr; w->wq_cap = 0;
+        GF_HIP(hipMalloc((void**)&w->d_wq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)need_w));
+        GF_HIP(hipMalloc((void**)&w->d_t2sn, sizeof(double) * 18 * (size_t)need_w));
+        hdr.cap = (unsigned int)need_w;
+        GF_HIP(hipMemcpyAsync(w->d_wq, &hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
+        GF_HIP(hipStreamSynchronize(st));
+        w->wq_cap = need_w;
+    }
+    return GF_OK;
+}
+
+// One BSM launch with or without the verdict's workspace (the stream's, locked for the duration of the launches)
+int launch_bsm_on(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, int with_llh, double* d_lnprob, double* d_fr,
+                  int32_t* d_status, const char* what)
+{
+    hipError_t e;
+    if (!d_status) {
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, with_llh, d_lnprob, d_fr, nullptr,
+                          nullptr, 0, nullptr, 0, nullptr, nullptr, m->cus, st);
+    } else {
+        UniWork* w = work_for(m->device, st);
+        if (!w) return GF_ERR_ALLOC;
+        std::lock_guard<std::mutex> lk(w->mu);
+        const int rq = ensure_uq(w, m->hb.nbins, st, layout, n);
+        if (rq != GF_OK) return rq;
+        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, with_llh, d_lnprob, d_fr, d_status,
+                          w->d_uq, w->uq_cap, n >= GF_TIER2_SPLIT_MIN ? w->d_wq : nullptr, w->wq_cap, w->d_t2sn, w->h_seen, m->cus, st);
+    }
+    if (e != hipSuccess) return hip_fail(e, what);
     return GF_OK;
 }
 
@@ -298,14 +384,8 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
                   int32_t* d_status)
 {
     if (n == 0) return GF_OK;
-    hipError_t e;
-    if (m->c.mode == GF_MODE_BSM_GAUSS) {
-        if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
-        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 1, d_lnprob, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN && m->d_t2sn ? m->d_wq : nullptr, m->d_t2sn, m->h_seen, m->cus, st);
-    }
-    else
-        e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
+    if (m->c.mode == GF_MODE_BSM_GAUSS) return launch_bsm_on(m, st, d_theta, layout, n, 1, d_lnprob, d_fr, d_status, "lnprob launch");
+    const hipError_t e = gf_launch_lnprob_sm(m->c, m->d_ptab, d_theta, layout, n, d_lnprob, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "lnprob launch");
     return GF_OK;
 }
@@ -313,14 +393,8 @@ int launch_lnprob(gf_model* m, hipStream_t st, const double* d_theta, int layout
 int launch_propagate(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, double* d_fr, int32_t* d_status)
 {
     if (n == 0) return GF_OK;
-    hipError_t e;
-    if (m->c.mode == GF_MODE_BSM_GAUSS) {
-        if (d_status) { const int rq = ensure_uq(m, st, layout, n); if (rq != GF_OK) return rq; }
-        e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, 0, nullptr, d_fr, d_status,
-                          d_status ? m->d_uq : nullptr, m->uq_cap, d_status && n >= GF_TIER2_SPLIT_MIN && m->d_t2sn ? m->d_wq : nullptr, m->d_t2sn, m->h_seen, m->cus, st);
-    }
-    else
-        e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
+    if (m->c.mode == GF_MODE_BSM_GAUSS) return launch_bsm_on(m, st, d_theta, layout, n, 0, nullptr, d_fr, d_status, "propagate launch");
+    const hipError_t e = gf_launch_propagate_sm(m->c, d_theta, layout, n, d_fr, d_status, m->cus, st);
     if (e != hipSuccess) return hip_fail(e, "propagate launch");
     return GF_OK;
 }
@@ -610,10 +684,6 @@ void gf_model_destroy(gf_model* m)
     if (m->d_status) (void)hipFree(m->d_status);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
     if (m->d_cube) (void)hipFree(m->d_cube);
-    if (m->d_uq) (void)hipFree(m->d_uq);
-    if (m->d_wq) (void)hipFree(m->d_wq);
-    if (m->d_t2sn) (void)hipFree(m->d_t2sn);
-    if (m->h_seen) (void)hipHostFree(m->h_seen);
     delete m;
 }
 
@@ -646,6 +716,21 @@ int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int lay
     if (!m || n < 0) return GF_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(m->call_mu);
     return launch_lnprob(m, (hipStream_t)stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
+}
+
+// internal: while `on`, every arbitration launch on `stream` takes the full grid whatever the previous one found
+// (gf_launch_uni_resolve); a workspace is created if the stream has none yet
+void gf_internal_full_arbitration_grids(int device, void* stream, int on)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES) return;
+    UniWork* w = work_for(device, (hipStream_t)stream);
+    if (!w) return;
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (!w->h_seen) {
+        if (hipHostMalloc((void**)&w->h_seen, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w->h_seen = nullptr; return; }
+        w->h_seen[0] = 0xffffffffu;
+    }
+    w->h_seen[1] = on ? 1u : 0u;
 }
 
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,

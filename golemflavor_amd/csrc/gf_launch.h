@@ -15,11 +15,11 @@ hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64
                           int cus, hipStream_t s);
 // BSM (flux-averaged) path; `with_llh` = 0 -> composition only (propagate), 1 -> lnprob
 // `uq`, `uq_cap`: the model's unitarity-arbitration queue and its capacity in items (NULL / 0 when status == NULL);
-// `wq`: its walker queue for the deferred tier 2 (capacity >= uq_cap / nbins), NULL = tiers 1-2 inline; `t2sn`: [capacity of wq][18]
+// `wq`, `wq_cap`: its walker queue for the deferred tier 2, NULL = tiers 1-2 inline; `t2sn`: [wq_cap][18]
 // doubles, where the evaluation kernel leaves the Hamiltonian terms of the walkers it queues; `seen`: see
 // gf_launch_uni_resolve
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
                          double* t2sn, unsigned int* seen, int cus, hipStream_t s);
 // gf_unitarity.hip: settles the (walker, bin) pairs queued by the evaluation kernel in emulated x87 arithmetic; a pair the
 // reference would raise on turns status[walker] into NON_UNITARY and lnprob[walker] (if given) into NaN.  `max_items`

@@ -526,6 +526,7 @@ int gf_model_constants(gf_model* m, const GfCommon** c, const GfBsm** d_bsm, con
 void gf_internal_set_error(const char* msg);
 int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
                        double* d_fr, int32_t* d_status);
+void gf_internal_full_arbitration_grids(int device, void* stream, int on);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
                           int32_t* d_status);
 }
@@ -1032,12 +1033,18 @@ int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double
     hipStream_t st = (hipStream_t)stream;
     const int64_t per_chain = s->nstored * s->nwalkers;
     int rc = GF_OK;
+    // the chains are enqueued faster than they run, so the arbitration grid of each would follow what some EARLIER chain found,
+    // and the chains of a scan differ (its high-scale grid points sit in the failing region, the others have empty queues):
+    // full grids throughout, ~30 us per chain (measured: the hint left 57 of 64 chains of the C4 scan on a sixth of the
+    // GPU, 114 ms of arbitration instead of ~20)
+    gf_internal_full_arbitration_grids(device0, stream, 1);
     for (int ch = 0; ch < s->nchains && rc == GF_OK && per_chain > 0; ++ch) {
         gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
         const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
         rc = gf_model_propagate_on(mc, stream, d_theta, GF_LAYOUT_AOS, per_chain, d_fr + (size_t)ch * per_chain * 3,
                                    d_status ? d_status + (size_t)ch * per_chain : nullptr);
     }
+    gf_internal_full_arbitration_grids(device0, stream, 0);
     GFS_HIP(hipStreamSynchronize(st));
     return rc;
 }

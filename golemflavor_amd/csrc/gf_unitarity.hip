@@ -116,7 +116,7 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
 {
     (void)ndim;
     int64_t expect = max_items;
-    if (seen) {
+    if (seen && seen[1] == 0) {               // seen[1] (host only): the caller asked for full grids (gf_internal_full_arbitration_grids)
         const int64_t last = (int64_t)__atomic_load_n(seen, __ATOMIC_RELAXED);     // 0xffffffff: nothing seen yet
         expect = 2 * last < max_items ? 2 * last : max_items;
     }
