@@ -51,9 +51,6 @@ using namespace gfdev;
 #endif
 // (the generic-width instances, NDIM = 0, index the row at run time and need ~180: two waves)
 #define GF_BSM_WAVES(UM, ND) ((ND) == 0 ? 2 : (UM) == UNI_NONE ? GF_BSM_WAVES_NONE : (UM) == UNI_DEFER ? GF_BSM_WAVES_DEFER : GF_BSM_WAVES_INLINE)
-// LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
-// SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
-// walkers per tile.  Results are bitwise those of LPW = 1.
 // Push the undecided bins of walker `i` (bit k of `amb` = energy bin k) onto the arbitration queue
 __device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t i, unsigned long long amb)
 {
@@ -64,7 +61,11 @@ __device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t
         if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)i * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
 }
 
-// UNI_MODE (gf_bsm_device.hpp): UNI_NONE no status; UNI_INLINE tiers 1-2 inside the evaluation (small batches);
+// LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
+// SIMDs): LPW adjacent lanes share a walker and split its energy bins (flux_average); a wave then covers 64 / LPW
+// walkers per tile.  Results are bitwise those of LPW = 1.
+// UNI_MODE (gf_bsm_device.hpp): UNI_NONE no status; UNI_INLINE tiers 1-2 inside the kernel, as a second phase for the walkers tier 1
+// does not clear (small batches);
 // UNI_DEFER the evaluation only notes the walkers tier 1 does not clear (`wq`) and k_bsm_tier2 runs tier 2 on those.
 template <int NDIM, bool WITH_LLH, int UNI_MODE, int LPW>
 __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tb,
