@@ -82,7 +82,17 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
     const GfCommon& c = *cp;
     constexpr int WPT = GF_WAVE / LPW;                                  // walkers per wave tile
     extern __shared__ __attribute__((aligned(16))) double fdyn[];        // LPW > 1: per lane group [nbins][3] + [LPW]
-    __shared__ __attribute__((aligned(16))) double tiles[GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
+    // PREFETCH (one lane per walker, compile-time row width): the next tile of theta is copied HBM -> LDS by the LDS-DMA path
+    // (global_load_lds_dwordx4: no VGPR destination, nothing held across the bin loop) into the other of two tile buffers
+    // while this tile is evaluated.  At 12 columns the exposed load latency was 6 % of the kernel (every tile re-reading
+    // the first one: 0.577 ms against 0.612), at 7 columns 1 %; the copy recovers 2-3.5 % (0.594 ms; 0.647 against 0.670
+    // with status), profiles/r02/ab_bsm_variants.txt.
+#ifdef GF_BSM_NO_PREFETCH
+    constexpr bool PREFETCH = false;
+#else
+    constexpr bool PREFETCH = NDIM > 0 && LPW == 1;
+#endif
+    __shared__ __attribute__((aligned(16))) double tiles[PREFETCH ? 2 : 1][GF_WAVES_PER_BLOCK][GF_WAVE * (NDIM ? NDIM : GF_MAX_DIM)];
     __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
     double* ttab = ctab + GF_MAX_DIM * 4;       // texture projector entries, see flux_average
     if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
@@ -96,21 +106,55 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
     }
     __syncthreads();
     const int lane = threadIdx.x & (GF_WAVE - 1);
-    const int wave = threadIdx.x / GF_WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / GF_WAVE);   // uniform, and the compiler may know: tile indices and
+                                                                              // addresses stay in scalar registers
     const int ndim = NDIM ? NDIM : c.ndim;
     const int sub = LPW > 1 ? lane % LPW : 0;
     double* fgrp = LPW > 1 ? fdyn + (threadIdx.x / LPW) * GF_FGRP_DOUBLES(tb->nbins, LPW) : nullptr;
-    double* tile = tiles[wave];
-    // UNI_DEFER: walkers waiting to be queued for k_bsm_tier2, per wave (a tile adds at most 64 to fewer than 64)
-    __shared__ int64_t pend[UNI_MODE == UNI_DEFER ? GF_WAVES_PER_BLOCK : 1][UNI_MODE == UNI_DEFER ? 2 * GF_WAVE : 1];
+    double* tile = tiles[0][wave];
+    // UNI_DEFER: walkers waiting to be queued for k_bsm_tier2, per wave (a tile adds at most 64 to fewer than 64); indices
+    // within this launch's piece of the batch, which holds fewer than 2^32 walkers
+    __shared__ unsigned int pend[UNI_MODE == UNI_DEFER ? GF_WAVES_PER_BLOCK : 1][UNI_MODE == UNI_DEFER ? 2 * GF_WAVE : 1];
     int npend = 0;
     const int64_t ntiles = (n + WPT - 1) / WPT;
     const int64_t stride = (int64_t)gridDim.x * GF_WAVES_PER_BLOCK;
+    bool staged = false;                                                 // PREFETCH: `tile` already holds this tile
     for (int64_t t = (int64_t)blockIdx.x * GF_WAVES_PER_BLOCK + wave; t < ntiles; t += stride) {
         const int64_t w0 = t * WPT;
         const int64_t nend = (LPW > 1 && w0 + WPT < n) ? w0 + WPT : n;     // stage this tile's WPT rows only
-        stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane, nend);
-        const int64_t i = w0 + lane / LPW;
+        // PREFETCH: does this wave have a next tile, and is it a whole one of an AoS batch?  (64 x NDIM doubles, contiguous in
+        // memory and in LDS: wave-instruction j moves the 16-B vectors j * 64 + lane, LDS address = uniform base + 16 * lane)
+        bool prefetched = false;
+        double* tile_next = tile;
+        // (the lane through an empty asm: otherwise per-lane addresses and indices -- lnprob + lane, the staging offsets ... --
+        // are formed once ahead of the tile loop and held, or spilled, through all of it)
+        int lane_t = lane;
+        if (PREFETCH) asm volatile("" : "+v"(lane_t));
+        if (PREFETCH) {
+            if (!staged) stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane_t, nend);
+            tile_next = tiles[tile == tiles[0][wave] ? 1 : 0][wave];
+            prefetched = layout == 0 && (t + stride + 1) * GF_WAVE <= n;
+        } else {
+            stage_theta<NDIM>(theta, layout, n, w0, ndim, tile, lane, nend);
+        }
+        auto start_next_tile = [&]() {
+            if (PREFETCH && prefetched) {
+                // (the offset through an empty asm: otherwise the address is formed at the top of the tile and carried, or
+                // spilled, through the prologue, which is where the kernel's register peak is)
+                int zero = 0, ln = lane;
+                asm volatile("" : "+s"(zero), "+v"(ln));
+                const double* src = theta + (t + stride + zero) * GF_WAVE * (NDIM ? NDIM : 1);
+                constexpr int NVEC = GF_WAVE * (NDIM ? NDIM : 2) / 2;
+#pragma unroll
+                for (int j = 0; j < (NVEC + GF_WAVE - 1) / GF_WAVE; ++j) {
+                    const int v = j * GF_WAVE + ln;
+                    if (v < NVEC)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * v),
+                                                         (__attribute__((address_space(3))) void*)(tile_next + 2 * j * GF_WAVE), 16, 0, 0);
+                }
+            }
+        };
+        const int64_t i = w0 + lane_t / LPW;
         bool defer = false;
         if (i < n) {
             const double* row = tile + (lane / LPW) * ndim;
@@ -128,18 +172,21 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
             double fr[3] = {gf_nan(), gf_nan(), gf_nan()};
             double val = -gf_inf();
             int st = ST_OUT_OF_PRIOR;
-            if (inbox) {
+            // a tile that prefetches takes every lane through the evaluation (the copy is started from inside it and must be
+            // started by the whole wave); the results of walkers outside the prior box are discarded below
+            if (inbox || (PREFETCH && prefetched)) {
                 UniAcc acc = {0.0, 0.0, 0ull, 2.0};
-                flux_average<UNI_MODE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp, UNI_MODE == UNI_DEFER ? t2sn + i * GF_SN_DOUBLES : nullptr);
+                flux_average<UNI_MODE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp, UNI_MODE == UNI_DEFER ? t2sn + i * GF_SN_DOUBLES : nullptr,
+                                            start_next_tile);
                 st = ST_OK;
                 if (CHECK_UNI) {
                     if (tb->uni_lo < 0.0) fr[0] = acc.est_max * (1.0 / UNI_EST_SCALE);  // diagnostics (GF_UNI_DUMP): the estimate itself
                     if (!(acc.clear_max < tb->uni_hi)) st = ST_NON_UNITARY;
                     // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
                     // walker counts as unitary
-                    else if (acc.amb != 0 && sub == 0 && uq) queue_pairs(uq, i, acc.amb);
+                    else if (inbox && acc.amb != 0 && sub == 0 && uq) queue_pairs(uq, i, acc.amb);
                 }
-                if (UNI_MODE == UNI_DEFER) defer = acc.a_min < tb->uni_a_ok;      // tier 1 does not clear this walker
+                if (UNI_MODE == UNI_DEFER) defer = inbox && acc.a_min < tb->uni_a_ok;      // tier 1 does not clear this walker
                 if (WITH_LLH) {
                     // llh.py:109-112: fr -> fr_to_angles -> (Gaussian substitute) angles_to_fr is the
                     // identity on a normalised composition up to rounding
@@ -149,7 +196,16 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
                     if (st == ST_OK) st = ST_NAN;
                 }
                 if (st == ST_NON_UNITARY) val = gf_nan();              // the reference raises here
+                if (!inbox) {                                          // evaluated for the wave's sake only
+                    st = ST_OUT_OF_PRIOR;
+                    val = -gf_inf();
+                    fr[0] = fr[1] = fr[2] = gf_nan();
+                }
             }
+            // the next tile's DMA has had the whole bin loop to land: retire it here, AHEAD of this tile's result stores (vmcnt
+            // counts those too, and they are then left to drain behind the next tile's arithmetic).  Every tile has a walker
+            // with i < n, so every wave passes here.
+            if (PREFETCH && prefetched) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (sub == 0) {
                 if (WITH_LLH) lnprob[i] = val;
                 if (fr_out) { fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2]; }
@@ -162,7 +218,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
             // 4 M walkers -- cost the evaluation kernel 18 %, profiles/r02/bsm_defer_atomics.txt.)
             const unsigned long long m = __ballot(defer);
             if (m != 0) {
-                if (defer) pend[wave][npend + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                if (defer) pend[wave][npend + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
                 npend += __popcll(m);                                    // wave-uniform
                 if (npend >= GF_WAVE) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -179,6 +235,10 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (PREFETCH) {
+            staged = prefetched;
+            tile = tile_next;
+        }
     }
     if (UNI_MODE == UNI_DEFER) {
         // what is left in the four lists goes out with one atomic per block

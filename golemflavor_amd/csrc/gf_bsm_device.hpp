@@ -366,13 +366,19 @@ __device__ __forceinline__ void hamiltonian_terms(const GfCommon& c, const GfBsm
 // per-bin compositions meet in LDS (`fgrp`: GF_FGRP_DOUBLES(nb, LPW) doubles, private to the lane group) and
 // every lane then runs the same in-order weighted sum, so the result is bitwise the LPW = 1 result on all LPW
 // lanes.  The walker's critical path drops from nb bins to ceil(nb / LPW).
-template <int UNI_MODE, int LPW = 1>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_terms`: called once the Hamiltonian terms are built, i.e. behind the last out-of-line call of the prologue (10^x)
+// and ahead of the bin loop -- where k_bsm starts the LDS-DMA copy of its next tile (a callee's entry waits for every
+// outstanding memory operation, so a copy started earlier would be waited for at once).
+template <int UNI_MODE, int LPW = 1, class Hook = NoHook>
 __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __restrict__ tb, const double* ttab,
                                              const double* row, double fr[3], UniAcc& acc, int sub = 0,
-                                             double* fgrp = nullptr, double* sn_out = nullptr)
+                                             double* fgrp = nullptr, double* sn_out = nullptr, Hook after_terms = Hook())
 {
     Herm3 S, N;
     hamiltonian_terms(c, tb, ttab, row, S, N);
+    after_terms();
     // the smallest SM weight over the bins, a_k = 1 / (1 + (v_k / u_k) trN / trS), from the largest v_k / u_k of the table
     // (the traces as bin_invariants forms them)
     if (UNI_MODE == UNI_DEFER || UNI_MODE == UNI_INLINE) {
