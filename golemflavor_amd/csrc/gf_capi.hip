@@ -116,12 +116,14 @@ struct gf_model {
     int device = 0;
     int cus = 256;
     // staging for the host-buffer entry points (grown on demand, reused across calls)
-    int64_t cap = 0;
+    int64_t cap = 0;             // rows the device buffers hold
     double* d_theta = nullptr;
     double* d_out = nullptr;     // lnprob [cap] then fr [3 cap]
     int32_t* d_status = nullptr;
-    void* h_pin = nullptr;       // pinned mirror: theta | lnprob | fr | status
+    int64_t hcap = 0;            // rows the pinned mirror holds (large batches stream through it in chunks: run_host)
+    void* h_pin = nullptr;       // pinned mirror: theta [hcap][ndim] | lnprob [hcap] | fr [hcap][3] | status [hcap]
     size_t h_pin_bytes = 0;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};   // the chunk pipeline's slot events
     double* d_cube = nullptr;    // gf_lnprob_cube_batch: the unit-cube rows on the device
     size_t cube_cap = 0;
     // unitarity arbitration queue (BSM models, grown on demand when a status array is requested)
@@ -270,23 +272,31 @@ void pool_release(int device, hipStream_t stream, void* block)
     if (block) (void)hipFree(block);
 }
 
-int ensure_staging(gf_model* m, int64_t n)
+// device buffers for `n` rows, pinned mirror for `n_pin` rows (n_pin < n: the batch streams through the mirror in chunks)
+int ensure_staging(gf_model* m, int64_t n, int64_t n_pin)
 {
-    if (n <= m->cap) return GF_OK;
-    int64_t cap = m->cap ? m->cap : 1024;
-    while (cap < n) cap *= 2;
-    if (m->d_theta) (void)hipFree(m->d_theta);
-    if (m->d_out) (void)hipFree(m->d_out);
-    if (m->d_status) (void)hipFree(m->d_status);
-    if (m->h_pin) (void)hipHostFree(m->h_pin);
-    m->d_theta = nullptr; m->d_out = nullptr; m->d_status = nullptr; m->h_pin = nullptr; m->cap = 0;
     const size_t nd = (size_t)m->c.ndim;
-    GF_HIP(hipMalloc((void**)&m->d_theta, sizeof(double) * nd * cap));
-    GF_HIP(hipMalloc((void**)&m->d_out, sizeof(double) * 4 * cap));
-    GF_HIP(hipMalloc((void**)&m->d_status, sizeof(int32_t) * cap));
-    m->h_pin_bytes = sizeof(double) * (nd + 4) * cap + sizeof(int32_t) * cap;
-    GF_HIP(hipHostMalloc(&m->h_pin, m->h_pin_bytes, hipHostMallocDefault));
-    m->cap = cap;
+    if (n > m->cap) {
+        int64_t cap = m->cap ? m->cap : 1024;
+        while (cap < n) cap *= 2;
+        if (m->d_theta) (void)hipFree(m->d_theta);
+        if (m->d_out) (void)hipFree(m->d_out);
+        if (m->d_status) (void)hipFree(m->d_status);
+        m->d_theta = nullptr; m->d_out = nullptr; m->d_status = nullptr; m->cap = 0;
+        GF_HIP(hipMalloc((void**)&m->d_theta, sizeof(double) * nd * cap));
+        GF_HIP(hipMalloc((void**)&m->d_out, sizeof(double) * 4 * cap));
+        GF_HIP(hipMalloc((void**)&m->d_status, sizeof(int32_t) * cap));
+        m->cap = cap;
+    }
+    if (n_pin > m->hcap) {
+        int64_t hcap = m->hcap ? m->hcap : 1024;
+        while (hcap < n_pin) hcap *= 2;
+        if (m->h_pin) (void)hipHostFree(m->h_pin);
+        m->h_pin = nullptr; m->hcap = 0;
+        m->h_pin_bytes = sizeof(double) * (nd + 4) * hcap + sizeof(int32_t) * hcap;
+        GF_HIP(hipHostMalloc(&m->h_pin, m->h_pin_bytes, hipHostMallocDefault));
+        m->hcap = hcap;
+    }
     return GF_OK;
 }
 
@@ -683,6 +693,10 @@ void gf_model_destroy(gf_model* m)
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_status) (void)hipFree(m->d_status);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
+    for (int k = 0; k < 2; ++k) {
+        if (m->ev_up[k]) (void)hipEventDestroy(m->ev_up[k]);
+        if (m->ev_down[k]) (void)hipEventDestroy(m->ev_down[k]);
+    }
     if (m->d_cube) (void)hipFree(m->d_cube);
     delete m;
 }
@@ -742,6 +756,70 @@ int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int 
 }
 
 // ---- host-buffer entry points ------------------------------------------------------------
+// Rows per chunk of the large-batch pipeline, and the batch size from which it is used.  A large batch streams through two
+// pinned slots: the host copies chunk c + 1 into its slot while chunk c crosses PCIe (and the other way round for the
+// results).  Copying the whole batch into a pinned mirror first and transferring it then -- the path below this size, where
+// it is one memcpy and one transfer -- runs at 1 / (1/33 + 1/57) = 21 GB/s on the MI355X box, the pipeline at the slower of
+// the two (tools/h2d_probe.hip); the mirror of a 4 M-row batch also took 0.1 s to allocate (hipHostMalloc: 4.7 GB/s).
+constexpr int64_t PIPE_CHUNK_ROWS = 65536;
+constexpr int64_t PIPE_MIN_ROWS = 4 * PIPE_CHUNK_ROWS;
+
+static int run_host_pipelined(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status, bool with_llh)
+{
+    constexpr int64_t CH = PIPE_CHUNK_ROWS;
+    int rc = ensure_staging(m, n, 2 * CH);
+    if (rc != GF_OK) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if (!m->ev_up[k]) GF_HIP(hipEventCreateWithFlags(&m->ev_up[k], hipEventDisableTiming));
+        if (!m->ev_down[k]) GF_HIP(hipEventCreateWithFlags(&m->ev_down[k], hipEventDisableTiming));
+    }
+    const size_t nd = (size_t)m->c.ndim;
+    double* h_theta = (double*)m->h_pin;
+    double* h_out = h_theta + nd * m->hcap;
+    double* h_fr = h_out + m->hcap;
+    int32_t* h_st = (int32_t*)(h_fr + 3 * m->hcap);
+    const int64_t nchunks = (n + CH - 1) / CH;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int slot = (int)(c & 1);
+        const int64_t off = c * CH, len = n - off < CH ? n - off : CH;
+        if (c >= 2) GF_HIP(hipEventSynchronize(m->ev_up[slot]));        // the slot's previous chunk has left for the device
+        std::memcpy(h_theta + nd * CH * slot, theta + nd * off, sizeof(double) * nd * len);
+        GF_HIP(hipMemcpyAsync(m->d_theta + nd * off, h_theta + nd * CH * slot, sizeof(double) * nd * len, hipMemcpyHostToDevice, m->stream));
+        GF_HIP(hipEventRecord(m->ev_up[slot], m->stream));
+    }
+    double* d_ln = m->d_out;
+    double* d_fr = m->d_out + m->cap;
+    if (with_llh)
+        rc = launch_lnprob(m, m->stream, m->d_theta, GF_LAYOUT_AOS, n, d_ln, fr ? d_fr : nullptr, status ? m->d_status : nullptr);
+    else
+        rc = launch_propagate(m, m->stream, m->d_theta, GF_LAYOUT_AOS, n, d_fr, status ? m->d_status : nullptr);
+    if (rc != GF_OK) return rc;
+    // results: chunk c comes down into its slot while the host copies chunk c - 1 out of the other (the transfers follow the
+    // kernel, and with it every upload that read these slots, in stream order)
+    auto copy_out = [&](int64_t c) {
+        const int slot = (int)(c & 1);
+        const int64_t off = c * CH, len = n - off < CH ? n - off : CH;
+        if (with_llh) std::memcpy(lnprob + off, h_out + CH * slot, sizeof(double) * len);
+        if (fr) std::memcpy(fr + 3 * off, h_fr + 3 * CH * slot, sizeof(double) * 3 * len);
+        if (status) std::memcpy(status + off, h_st + CH * slot, sizeof(int32_t) * len);
+    };
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int slot = (int)(c & 1);
+        const int64_t off = c * CH, len = n - off < CH ? n - off : CH;
+        if (with_llh) GF_HIP(hipMemcpyAsync(h_out + CH * slot, d_ln + off, sizeof(double) * len, hipMemcpyDeviceToHost, m->stream));
+        if (fr) GF_HIP(hipMemcpyAsync(h_fr + 3 * CH * slot, d_fr + 3 * off, sizeof(double) * 3 * len, hipMemcpyDeviceToHost, m->stream));
+        if (status) GF_HIP(hipMemcpyAsync(h_st + CH * slot, m->d_status + off, sizeof(int32_t) * len, hipMemcpyDeviceToHost, m->stream));
+        GF_HIP(hipEventRecord(m->ev_down[slot], m->stream));
+        if (c >= 1) {
+            GF_HIP(hipEventSynchronize(m->ev_down[slot ^ 1]));
+            copy_out(c - 1);
+        }
+    }
+    GF_HIP(hipEventSynchronize(m->ev_down[(nchunks - 1) & 1]));
+    copy_out(nchunks - 1);
+    return GF_OK;
+}
+
 static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status,
                     bool with_llh)
 {
@@ -751,13 +829,15 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     std::lock_guard<std::mutex> lk(m->call_mu);
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
-    int rc = ensure_staging(m, n);
+    static const bool pipe_off = std::getenv("GF_NO_HOST_PIPELINE") != nullptr;  // diagnostics / A-B
+    if (n >= PIPE_MIN_ROWS && !pipe_off) return run_host_pipelined(m, theta, n, lnprob, fr, status, with_llh);
+    int rc = ensure_staging(m, n, n);
     if (rc != GF_OK) return rc;
     const size_t nd = (size_t)m->c.ndim;
     double* h_theta = (double*)m->h_pin;
-    double* h_out = h_theta + nd * m->cap;
-    double* h_fr = h_out + m->cap;
-    int32_t* h_st = (int32_t*)(h_fr + 3 * m->cap);
+    double* h_out = h_theta + nd * m->hcap;
+    double* h_fr = h_out + m->hcap;
+    int32_t* h_st = (int32_t*)(h_fr + 3 * m->hcap);
     std::memcpy(h_theta, theta, sizeof(double) * nd * n);
     // Small batches (emcee's half-ensemble of a 100-walker chain is 50 rows): the kernel reads theta from and
     // writes its results to the pinned, device-mapped staging buffer directly -- one launch and one stream
@@ -814,13 +894,13 @@ int gf_lnprob_cube_batch(gf_model* m, const double* cube, int64_t n, int nscan, 
     std::lock_guard<std::mutex> lk(m->call_mu);
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
-    int rc = ensure_staging(m, n);
+    int rc = ensure_staging(m, n, n);
     if (rc != GF_OK) return rc;
     const size_t nd = (size_t)m->c.ndim;
     double* h_cube = (double*)m->h_pin;                      // the theta slot of the pinned mirror holds the (smaller) cube
-    double* h_out = h_cube + nd * m->cap;
-    double* h_fr = h_out + m->cap;
-    int32_t* h_st = (int32_t*)(h_fr + 3 * m->cap);
+    double* h_out = h_cube + nd * m->hcap;
+    double* h_fr = h_out + m->hcap;
+    int32_t* h_st = (int32_t*)(h_fr + 3 * m->hcap);
     double* d_ln = m->d_out;
     double* d_fr = m->d_out + m->cap;
     // device side: the cube rows get their own buffer, grown on demand (d_theta receives the expanded rows)

@@ -356,6 +356,44 @@ def test_status_does_not_depend_on_what_the_model_ran_before():
     assert 0.1 < np.mean(want[2] == _lib.GF_ST_NON_UNITARY) < 0.3
 
 
+def test_large_host_batches_stream_through_the_pinned_slots(golden):
+    """From 262 144 rows on, a host batch streams through two pinned slots in chunks of 65 536 rows (run_host_pipelined) instead
+    of being mirrored whole: lnprob, composition and status must be those of the device-resident path on the same rows, bit for
+    bit -- SM and BSM (through the failing region), a ragged last chunk, a second call on the same model, and propagate."""
+    from common import notebook_sets, uniform_theta
+    rng = np.random.default_rng(17)
+    n = 4 * 65536 + 4321
+    _, ps = notebook_sets(golden)
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[::1000, 0] = 2.0                                             # some rows outside the prior box
+    with Model(compile_model(ps, "SM_GAUSS", bestfit_fr=golden["g6_bestfit_fr"], smearing=0.02)) as m:
+        d_th = m.alloc(th.nbytes).upload(th)
+        d_out, d_fr, d_st = m.alloc(8 * n), m.alloc(24 * n), m.alloc(4 * n)
+        m.lnprob_device(d_th.ptr, n, d_out.ptr, d_fr.ptr, d_st.ptr); m.sync()
+        want = (d_out.download((n,)), d_fr.download((n, 3)), d_st.download((n,), dtype=np.int32))
+        for _ in range(2):
+            got = m.lnprob(th, want_fr=True)
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b, equal_nan=True)
+        assert np.isneginf(want[0][::1000]).all() and (want[2][::1000] == _lib.GF_ST_OUT_OF_PRIOR).all()
+    ps7 = Cf.texture_paramset(6)
+    lo, hi = Cf.SCALE_BOUNDARIES[6]
+    th = uniform_theta(ps7, n, rng, seeds=True)
+    th[:, 6] = rng.uniform(lo, hi, n)
+    with Model(compile_model(ps7, "BSM_GAUSS", texture=Texture.OEU, dimension=6, binning=BIN_EDGES, source_ratio=(0., 1., 0.),
+                             bestfit_fr=(1 / 3,) * 3, smearing=0.02)) as m:
+        d_th = m.alloc(th.nbytes).upload(th)
+        d_out, d_fr, d_st = m.alloc(8 * n), m.alloc(24 * n), m.alloc(4 * n)
+        m.lnprob_device(d_th.ptr, n, d_out.ptr, d_fr.ptr, d_st.ptr); m.sync()
+        want = (d_out.download((n,)), d_fr.download((n, 3)), d_st.download((n,), dtype=np.int32))
+        got = m.lnprob(th, want_fr=True)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b, equal_nan=True)
+        pfr, pst = m.propagate(th)
+        assert np.array_equal(pst, want[2]) and np.array_equal(pfr, want[1], equal_nan=True)
+        assert 0.1 < np.mean(want[2] == _lib.GF_ST_NON_UNITARY) < 0.3
+
+
 def test_two_threads_share_one_model(golden):
     """The host-buffer entry points stage through buffers that belong to the model: two host threads hammering ONE model
     with different batches (sizes either side of the zero-copy limit, SM and BSM) must each get their own results."""
