@@ -94,8 +94,9 @@ class _SensPoint:
 
     def __init__(self, point, g, *, nwalkers, device, seed=25, smearing=0.02):
         dim, tex, source, scale = point
-        inj = fr_utils.fr_to_angles((1, 1, 1))
-        asimov, ps = Cf.fr_paramsets(dim, inj)
+        if dim not in self._paramsets:                        # the same for every grid point of a dimension; read-only here
+            self._paramsets[dim] = Cf.fr_paramsets(dim, fr_utils.fr_to_angles((1, 1, 1)))
+        asimov, ps = self._paramsets[dim]
         args = argparse.Namespace(source_ratio=np.array(source), dimension=dim, texture=tex, binning=Cf.default_bin_edges())
         self.f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=smearing, device=device, on_nonunitary="-inf")
         rng = np.random.default_rng(seed + g)
@@ -106,6 +107,7 @@ class _SensPoint:
         self.ndim, self.nwalkers, self.seed = 12, nwalkers, seed + g
 
     post_model = None
+    _paramsets = {}
 
     @staticmethod
     def assemble(samples, frs, status):
