@@ -341,7 +341,7 @@ __device__ __forceinline__ void hamiltonian_terms(const GfCommon& c, const GfBsm
     S = rank2(pick(row, c.idx_mass[0], c.mass_fixed[0]), c1r, c1i,
                           pick(row, c.idx_mass[1], c.mass_fixed[1]), c2r, c2i);
     // NP part, per walker: sc1 T1 + sc2 T2, sc2 = 10^logLam, sc1 = sc2/100   (fr.py:380-393)
-    const double sc2 = pow10_cold(pick(row, c.idx_scale, c.scale_fixed));
+    const double sc2 = pow10_scale(pick(row, c.idx_scale, c.scale_fixed));
     const double sc1 = sc2 / 100.0;
     if (tb->texture == TEX_NONE) {
         mixing_cols12(pick(row, c.idx_mm[0], c.mm_fixed[0]), pick(row, c.idx_mm[1], c.mm_fixed[1]),

@@ -197,11 +197,34 @@ __device__ __forceinline__ double fast_acos(double x)
     return x < 0.0 ? 3.141592653589793 - a : a;
 }
 
-// 10^x for the NP scale (fr.py:380 np.power(10., logLam)); once per walker, out of line.
-#ifdef GF_POW_INLINE            // A/B switch (tools/build_variants.sh)
-static __device__ __forceinline__ double pow10_cold(double x) { return pow(10.0, x); }
-#else
+// 10^x for the NP scale (fr.py:380 np.power(10., logLam)), once per walker.  The library pow(10, x) is ~200 instructions
+// behind a call; for |x| < 300 (every scale a paramset of the reference can hold: -72 ... -20) this is 22: n = rint(x log2 10),
+// r = x - n log10(2) by a two-constant Cody-Waite reduction (the high part has 33 bits: n * hi is exact), 10^r as the degree-14
+// Taylor polynomial of exp(r ln 10) on |r ln 10| <= 0.347 (truncation 4e-18), times 2^n.  <= 2 ulp against 50-digit values on
+// 20 000 arguments; the value enters the Hamiltonian linearly, the parity bar is 1e-10.  (The x87-faithful arbitration has
+// its own, correctly rounded 10^x: gf_x87.hpp.)  Anything else, NaN included, takes the library call.
 static __device__ __attribute__((noinline)) double pow10_cold(double x) { return pow(10.0, x); }
+#ifdef GF_POW_LIBRARY           // A/B switch (tools/build_variants.sh): the library call for every argument
+__device__ __forceinline__ double pow10_scale(double x) { return pow10_cold(x); }
+#else
+// (constants in constant memory for the reason given at GF_KTAB: as literals they would sit in 36 VGPRs across the bin loop)
+__constant__ double GF_P10TAB[18] = {
+    3.321928094887362, 0.30102999560767785, 5.630334806675098e-11,      // log2(10); log10(2): high 33 bits, the rest
+    1.3508629476223687e-06, 8.213412535439387e-06, 4.6371516642572196e-05, 0.00024166672554424694,   // ln(10)^k / k!, k = 14 ... 0
+    0.0011544997789984348, 0.00501392883377544, 0.019597694626478524, 0.06808936507443707, 0.2069958486968681,
+    0.5393829291955814, 1.171255148912267, 2.034678592293476, 2.650949055239199, 2.302585092994046, 1.0};
+__device__ __forceinline__ double pow10_scale(double x)
+{
+    if (!(fabs(x) < 300.0)) return pow10_cold(x);
+    const double* k = GF_P10TAB;
+    const double n = rint(x * k[0]);
+    double r = fma(-n, k[1], x);
+    r = fma(-n, k[2], r);
+    double p = k[3];
+#pragma unroll
+    for (int j = 4; j < 18; ++j) p = fma(p, r, k[j]);
+    return ldexp(p, (int)n);
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------
