@@ -376,6 +376,7 @@ hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBs
     if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
     if (wq && wq_cap < piece) piece = wq_cap;                            // ... and the walker queue of the deferred tier 2
+    if (piece > 64) piece &= ~(int64_t)63;                               // whole tiles: every piece starts 16-B aligned like the batch
     if (piece < 1) piece = 1;
     if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n
     for (int64_t w0 = 0; w0 < n; w0 += piece) {
