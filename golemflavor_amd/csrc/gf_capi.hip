@@ -318,11 +318,18 @@ constexpr int64_t UQ_MAX_ITEMS = 1 << 27;      // 1 GiB of items at most: ~6.7 M
 constexpr int64_t GF_TIER2_SPLIT_MIN = 65536;
 constexpr int64_t WQ_MAX_WALKERS = 1 << 23;    // per piece: 8.4 M walkers, 1.2 GB of side buffer
 
-int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n)
+// `items_limit` (out): how many items of the queue a piece of this batch may use (its capacity, or GF_UQ_MAX_ITEMS if smaller)
+int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int64_t* items_limit)
 {
     const int64_t nb = nbins > 0 ? nbins : 1;
     int64_t need = n * nb;
-    if (layout == GF_LAYOUT_AOS && need > UQ_MAX_ITEMS) need = UQ_MAX_ITEMS > nb ? UQ_MAX_ITEMS : nb;
+    int64_t max_items = UQ_MAX_ITEMS;
+    if (const char* e = std::getenv("GF_UQ_MAX_ITEMS")) {     // tests: a small queue, so that a modest batch is cut into pieces
+        const long long v = std::atoll(e);
+        if (v >= 65536 && v < UQ_MAX_ITEMS) max_items = v;
+    }
+    if (layout == GF_LAYOUT_AOS && need > max_items) need = max_items > nb ? max_items : nb;
+    *items_limit = layout == GF_LAYOUT_AOS ? (max_items > nb ? max_items : nb) : (int64_t)0x7fffffffffffLL;
     if (need > 0xffffffffLL) {
         std::snprintf(g_err, sizeof(g_err), "a structure-of-arrays batch of %lld walkers with a status array exceeds the arbitration queue", (long long)n);
         return GF_ERR_UNSUPPORTED;
@@ -381,10 +388,11 @@ int launch_bsm_on(gf_model* m, hipStream_t st, const double* d_theta, int layout
         UniWork* w = work_for(m->device, st);
         if (!w) return GF_ERR_ALLOC;
         std::lock_guard<std::mutex> lk(w->mu);
-        const int rq = ensure_uq(w, m->hb.nbins, st, layout, n);
+        int64_t limit = 0;
+        const int rq = ensure_uq(w, m->hb.nbins, st, layout, n, &limit);
         if (rq != GF_OK) return rq;
         e = gf_launch_bsm(m->c, m->d_common, m->d_bsm, m->hb.nbins, m->d_ptab, d_theta, layout, n, with_llh, d_lnprob, d_fr, d_status,
-                          w->d_uq, w->uq_cap, n >= GF_TIER2_SPLIT_MIN ? w->d_wq : nullptr, w->wq_cap, w->d_t2sn, w->h_seen, m->cus, st);
+                          w->d_uq, w->uq_cap < limit ? w->uq_cap : limit, n >= GF_TIER2_SPLIT_MIN ? w->d_wq : nullptr, w->wq_cap, w->d_t2sn, w->h_seen, m->cus, st);
     }
     if (e != hipSuccess) return hip_fail(e, what);
     return GF_OK;

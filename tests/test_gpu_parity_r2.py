@@ -356,6 +356,35 @@ def test_status_does_not_depend_on_what_the_model_ran_before():
     assert 0.1 < np.mean(want[2] == _lib.GF_ST_NON_UNITARY) < 0.3
 
 
+def test_batches_larger_than_the_arbitration_queue_are_cut_into_pieces(monkeypatch):
+    """A status batch whose (walker, bin) pairs exceed the arbitration queue (1 GiB = 6.7 M walkers of 20 bins) is cut into
+    pieces, each evaluated, tier-2'd and arbitrated in stream order.  With the queue limited to 2 M items (GF_UQ_MAX_ITEMS, read
+    per call) 300 001 walkers make three ragged pieces: results must equal those of a model that takes them in one piece."""
+    from common import uniform_theta
+    dim, tex = 6, Texture.OEU
+    ps = Cf.texture_paramset(dim)
+    lo, hi = Cf.SCALE_BOUNDARIES[dim]
+    rng = np.random.default_rng(31)
+    n = 300_001
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[:, -1] = rng.uniform(lo, hi, n)
+    kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(0., 1., 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    desc = compile_model(ps, "BSM_GAUSS", texture=tex, **kw)
+    with Model(desc) as m:
+        want = m.lnprob(th, want_fr=True)
+    monkeypatch.setenv("GF_UQ_MAX_ITEMS", "2000000")
+    with Model(desc) as m:
+        got = m.lnprob(th, want_fr=True)
+        d_th = m.alloc(th.nbytes).upload(th)
+        d_out, d_st = m.alloc(8 * n), m.alloc(4 * n)
+        m.lnprob_device(d_th.ptr, n, d_out.ptr, None, d_st.ptr); m.sync()
+        dev = (d_out.download((n,)), d_st.download((n,), dtype=np.int32))
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(dev[0], want[0], equal_nan=True) and np.array_equal(dev[1], want[2])
+    assert 0.1 < np.mean(want[2] == _lib.GF_ST_NON_UNITARY) < 0.3
+
+
 def test_large_host_batches_stream_through_the_pinned_slots(golden):
     """From 262 144 rows on, a host batch streams through two pinned slots in chunks of 65 536 rows (run_host_pipelined) instead
     of being mirrored whole: lnprob, composition and status must be those of the device-resident path on the same rows, bit for
