@@ -398,9 +398,6 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     const double s0 = c.src_fixed[0] * isrc, s1 = c.src_fixed[1] * isrc, s2 = c.src_fixed[2] * isrc;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int nb = tb->nbins;
-#ifdef GF_BIN_UNROLL1
-#pragma unroll 1
-#endif
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
         const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
