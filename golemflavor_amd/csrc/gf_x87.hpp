@@ -39,6 +39,23 @@
 #else
 #define GFX_HD
 #endif
+// The chain below is ~37 000 instructions when everything is inlined and every 3x3 loop unrolled: 150 KB of straight-line
+// code, far more than the instruction cache holds, with every wave somewhere else in it.  Measured on the arbitration of a
+// failing region (tools/ab_unitarity.sh, profiles/r02/ab_unitarity_code_size.txt): keeping the 3x3 loops rolled (GFX_ROLLED)
+// and the large, rarely called pieces out of line (GFX_BIG: the sine/cosine series, division, square root) is 18 % faster
+// (27 000 instructions).  Making functions of the small primitives as well (x_add, x_mul: 50-60 instructions each; 13 000
+// instructions in all) is 25 % SLOWER than the all-inline build, and of the complex product (320 instructions) no faster:
+// the call sequence and its register conventions cost what the instruction fetches save.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GFX87_INLINE_ALL)
+#define GFX_BIG __attribute__((noinline))
+#else
+#define GFX_BIG inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GFX87_UNROLL_ALL)
+#define GFX_ROLLED _Pragma("unroll 1")
+#else
+#define GFX_ROLLED
+#endif
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
@@ -166,10 +183,10 @@ GFX_HD inline bool x_is_zero(x87 a) { return a.hi == 0.0; }
 GFX_HD inline bool x_ge(x87 a, x87 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
 
 GFX_HD inline x87 x_add(x87 a, x87 b) { return round64(dd_add(as_dd(a), as_dd(b))); }
-GFX_HD inline x87 x_sub(x87 a, x87 b) { return round64(dd_sub(as_dd(a), as_dd(b))); }
+GFX_HD inline x87 x_sub(x87 a, x87 b) { return x_add(a, x_neg(b)); }      // dd_sub is dd_add of the negation: the same operations
 GFX_HD inline x87 x_mul(x87 a, x87 b) { return round64(dd_mul(as_dd(a), as_dd(b))); }
-GFX_HD inline x87 x_div(x87 a, x87 b) { return round64(dd_div(as_dd(a), as_dd(b))); }
-GFX_HD inline x87 x_sqrt(x87 a) { return round64(dd_sqrt(as_dd(a))); }
+GFX_HD GFX_BIG x87 x_div(x87 a, x87 b) { return round64(dd_div(as_dd(a), as_dd(b))); }
+GFX_HD GFX_BIG x87 x_sqrt(x87 a) { return round64(dd_sqrt(as_dd(a))); }
 GFX_HD inline x87 x_scale2(x87 a, double p2) { x87 r = {a.hi * p2, a.lo * p2}; return r; }    // exact: p2 a power of two
 
 // ---- transcendental functions, ~2^-100, for the (cold) chain ---------------------------------------------
@@ -179,7 +196,7 @@ GFX_HD inline x87 x_scale2(x87 a, double p2) { x87 r = {a.hi * p2, a.lo * p2}; r
 #define GFX_PIO2_3 (-1.4973849048591698e-33)
 
 // sin and cos of a double-double, |x| < ~1e4
-GFX_HD inline void dd_sincos(dd x, dd& sn, dd& cs)
+GFX_HD GFX_BIG void dd_sincos(dd x, dd& sn, dd& cs)
 {
     const double kf = nearbyint(x.hi * 0.6366197723675814);
     dd r = x;
@@ -391,6 +408,7 @@ GFX_HD inline void angles_to_u(const double ang[4], cx87 u[3][3])
     T[2][0] = c_scale(c23, ms13ep); T[2][1] = c_make(x_neg(s23), zero); T[2][2] = c_make(x_mul(c23, c13), zero);
     // u = T . p3
     const x87 ms12 = x_neg(s12);
+    GFX_ROLLED
     for (int i = 0; i < 3; ++i) {
         u[i][0] = c_add(c_scale(c12, T[i][0]), c_scale(ms12, T[i][1]));
         u[i][1] = c_add(c_scale(s12, T[i][0]), c_scale(c12, T[i][1]));
@@ -402,9 +420,11 @@ GFX_HD inline void angles_to_u(const double ang[4], cx87 u[3][3])
 GFX_HD inline void sandwich(const cx87 u[3][3], double w1, double w2, cx87 h[3][3])
 {
     const x87 xw1 = x_from(w1), xw2 = x_from(w2);
+    GFX_ROLLED
     for (int j = 0; j < 3; ++j) {
         const cx87 t1 = c_scale(xw1, c_conj(u[j][1]));                // (diag . U^+)[1][j]
         const cx87 t2 = c_scale(xw2, c_conj(u[j][2]));
+        GFX_ROLLED
         for (int i = 0; i < 3; ++i) h[i][j] = c_add(c_mul(u[i][1], t1), c_mul(u[i][2], t2));
     }
 }
@@ -417,6 +437,7 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
     cx87 tr2 = c_zero();
     {
         cx87 d[3];
+        GFX_ROLLED
         for (int i = 0; i < 3; ++i) {
             cx87 s = c_mul(h[i][0], h[0][i]);
             s = c_add(s, c_mul(h[i][1], h[1][i]));
@@ -447,6 +468,7 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
     E[2] = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(x_add(theta.re, twopi), theta.im), three))), third_a);   // fr.py:214
     cx87 x[3][3];
     const cx87 h10h02 = c_mul(h[1][0], h[0][2]), h21h10 = c_mul(h[2][1], h[1][0]), h12h20 = c_mul(h[1][2], h[2][0]);
+    GFX_ROLLED
     for (int k = 0; k < 3; ++k) {
         const cx87 A = c_sub(c_mul(h[1][2], c_sub(h[0][0], E[k])), h10h02);             // fr.py:216-218
         const cx87 B = c_sub(c_mul(h[2][0], c_sub(h[1][1], E[k])), h21h10);             // fr.py:220-222
@@ -460,7 +482,9 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
     }
     // fr.py:489: f = |x x^+|; |p_ji| = |p_ij| exactly (the same products, the sums negated)
     x87 f[3][3];
+    GFX_ROLLED
     for (int i = 0; i < 3; ++i)
+        GFX_ROLLED
         for (int j = i; j < 3; ++j) {
             cx87 s = c_mul(x[i][0], c_conj(x[j][0]));
             s = c_add(s, c_mul(x[i][1], c_conj(x[j][1])));
@@ -497,7 +521,9 @@ GFX_HD inline double bin_residual(const cx87 hsm[3][3], const cx87 hnp[3][3], do
     // scaling the two fp64 prefactors by 2^k scales every entry of ham by exactly 2^k
     const x87 xp = x_from(pre * p2), xe = x_from(epow * p2);
     cx87 h[3][3];
+    GFX_ROLLED
     for (int i = 0; i < 3; ++i)
+        GFX_ROLLED
         for (int j = 0; j < 3; ++j) h[i][j] = c_add(c_scale(xp, hsm[i][j]), c_scale(xe, hnp[i][j]));   // fr.py:386, 394-395
     return cardano_residual(h);
 }
