@@ -3,6 +3,7 @@
 // management and the launch calls.  There is deliberately no CPU evaluation path in this library.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -998,8 +999,35 @@ int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes
     if (!m || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
-    GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
-    GF_HIP(hipStreamSynchronize(m->stream));
+    // A large read-back (the chains of a scan: gigabytes into a fresh array): a copy into pages that are not mapped yet runs
+    // at page-fault speed (11-20 GB/s against 48-56, tools/pcie_probe.hip), and mapping them first (gf_host_prepare) costs
+    // 8 ms per GiB -- so a helper thread maps chunk k + 1 while chunk k crosses PCIe.  (One byte per page is written ahead of
+    // the copy that overwrites the page anyway.)
+    constexpr size_t D2H_PIPE_MIN = (size_t)256 << 20, D2H_CHUNK = (size_t)128 << 20;
+    static const bool pipe_off = std::getenv("GF_NO_D2H_PIPELINE") != nullptr;            // diagnostics / A-B
+    if (bytes < D2H_PIPE_MIN || pipe_off) {
+        GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
+        GF_HIP(hipStreamSynchronize(m->stream));
+        return GF_OK;
+    }
+    std::atomic<size_t> mapped{0};
+    char* dst = static_cast<char*>(dst_host);
+    std::thread mapper([&]() {
+        for (size_t off = 0; off < bytes; off += D2H_CHUNK) {
+            const size_t len = bytes - off < D2H_CHUNK ? bytes - off : D2H_CHUNK;
+            (void)gf_host_prepare(dst + off, len);
+            mapped.store(off + len, std::memory_order_release);
+        }
+    });
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < bytes && e == hipSuccess; off += D2H_CHUNK) {
+        const size_t len = bytes - off < D2H_CHUNK ? bytes - off : D2H_CHUNK;
+        while (mapped.load(std::memory_order_acquire) < off + len) std::this_thread::yield();
+        e = hipMemcpyAsync(dst + off, static_cast<const char*>(src_dev) + off, len, hipMemcpyDeviceToHost, m->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    }
+    mapper.join();
+    if (e != hipSuccess) return hip_fail(e, "gf_memcpy_d2h");
     return GF_OK;
 }
 

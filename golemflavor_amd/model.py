@@ -12,14 +12,16 @@ from ._lib import GF_LAYOUT_AOS, GF_LAYOUT_SOA, check  # noqa: F401
 
 
 PREPARE_MIN_BYTES = 32 << 20
+PREPARE_MAX_BYTES = 256 << 20      # from here on gf_memcpy_d2h maps the pages itself, chunk by chunk, overlapped with the copy
 
 
-def empty_for_download(shape, dtype=np.float64):
+def empty_for_download(shape, dtype=np.float64, copier_maps_pages=False):
     """np.empty whose pages are already mapped when it is big: a device-to-host copy into untouched memory runs at
     page-fault speed (11-20 GB/s on the MI355X box), into touched memory at PCIe speed (48-56 GB/s);
-    gf_host_prepare touches the pages from several threads (2 GiB in 17 ms)."""
+    gf_host_prepare touches the pages from several threads (2 GiB in 17 ms).  `copier_maps_pages`: the array goes to
+    gf_memcpy_d2h, which does this itself for large copies."""
     out = np.empty(shape, dtype=dtype)
-    if out.nbytes >= PREPARE_MIN_BYTES:
+    if out.nbytes >= PREPARE_MIN_BYTES and not (copier_maps_pages and out.nbytes >= PREPARE_MAX_BYTES):
         check(_lib.lib().gf_host_prepare(out.ctypes.data_as(C.c_void_p), out.nbytes), "gf_host_prepare")
     return out
 
@@ -53,7 +55,7 @@ class DeviceBuffer:
         return self
 
     def download(self, shape, dtype=np.float64, offset_bytes=0):
-        out = empty_for_download(shape, dtype)
+        out = empty_for_download(shape, dtype, copier_maps_pages=True)
         assert out.nbytes + offset_bytes <= self.nbytes
         src = C.c_void_p(self.ptr.value + offset_bytes)
         check(self.model._L.gf_memcpy_d2h(self.model._h, out.ctypes.data_as(C.c_void_p), src, out.nbytes), "d2h")
