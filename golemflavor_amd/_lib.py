@@ -111,6 +111,7 @@ SIGNATURES = {
     "gf_sampler_pending": (C.c_int, [_vp, C.POINTER(C.c_uint32), _dp, C.c_uint32]),
     "gf_sampler_postprocess_device": (C.c_int, [_vp, C.POINTER(_vp), _vp, _vp]),
     "gf_sampler_postprocess_rows_device": (C.c_int, [_vp, C.POINTER(_vp), _vp]),
+    "gf_sampler_postprocess_rows": (C.c_int, [_vp, C.POINTER(_vp), _dp]),
 }
 
 _lib = None

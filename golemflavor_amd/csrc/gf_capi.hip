@@ -741,6 +741,21 @@ int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int lay
     return launch_lnprob(m, (hipStream_t)stream, d_theta, layout, n, d_lnprob, d_fr, d_status);
 }
 
+// internal: a second stream from the device's pool (gf_sampler.hip: copies that overlap the sampler stream's kernels)
+int gf_internal_borrow_stream(int device, void** stream)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !stream) return GF_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    const hipError_t e = pool_stream(device, &st);
+    if (e != hipSuccess) return hip_fail(e, "pool_stream");
+    *stream = (void*)st;
+    return GF_OK;
+}
+void gf_internal_return_stream(int device, void* stream)          // idle (synchronised) streams only
+{
+    if (device >= 0 && device < POOL_MAX_DEVICES && stream) pool_release(device, (hipStream_t)stream, nullptr);
+}
+
 // internal: while `on`, every arbitration launch on `stream` takes the full grid whatever the previous one found
 // (gf_launch_uni_resolve); a workspace is created if the stream has none yet
 void gf_internal_full_arbitration_grids(int device, void* stream, int on)

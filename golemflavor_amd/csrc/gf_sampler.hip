@@ -527,6 +527,8 @@ void gf_internal_set_error(const char* msg);
 int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_lnprob,
                        double* d_fr, int32_t* d_status);
 void gf_internal_full_arbitration_grids(int device, void* stream, int on);
+int gf_internal_borrow_stream(int device, void** stream);
+void gf_internal_return_stream(int device, void* stream);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
                           int32_t* d_status);
 }
@@ -1081,6 +1083,76 @@ int gf_sampler_postprocess_rows_device(gf_sampler* s, gf_model* const* models, d
     if (rc != GF_OK) return rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess_rows_device");
+    return GF_OK;
+}
+
+// The scan's rows straight to the host.  The chains are post-processed in turn on the sampler's stream (everything is enqueued
+// at once); an event marks the end of every group of chains, and the host walks the groups: wait for the event, map the
+// destination pages of the group, copy it on a SECOND stream -- so the copies of finished groups overlap the evaluation (and
+// the x87 arbitration, which dominates a texture scan) of the later ones.
+int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* rows)
+{
+    if (!s || !rows) return GF_ERR_INVALID_ARG;
+    const GfCommon* c0; const GfBsm* tb; const double* ptab; void* stream; int device0;
+    if (gf_model_internal(s->model, &c0, &tb, &ptab, &stream, &device0) != GF_OK) return GF_ERR_INVALID_ARG;
+    for (int ch = 0; ch < s->nchains; ++ch) {
+        gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
+        const GfCommon* c; int device, cus, nbins;
+        if (gf_model_constants(mc, &c, &tb, &ptab, &device, &cus, &nbins) != GF_OK || c->ndim != s->ndim || device != device0)
+            return GF_ERR_INVALID_ARG;
+    }
+    GFS_HIP(hipSetDevice(device0));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per_chain = s->nstored * s->nwalkers;
+    if (per_chain == 0) { GFS_HIP(hipStreamSynchronize(st)); return GF_OK; }
+    const size_t width = 3 + (size_t)s->ndim, chain_bytes = sizeof(double) * width * (size_t)per_chain;
+    constexpr int MAX_GROUPS = 16;
+    const int per_group = (s->nchains + MAX_GROUPS - 1) / MAX_GROUPS;
+    const int ngroups = (s->nchains + per_group - 1) / per_group;
+    double *d_fr = nullptr, *d_rows = nullptr;
+    int32_t* d_st = nullptr;
+    void* copy_stream = nullptr;
+    hipEvent_t ev[MAX_GROUPS] = {};
+    int rc = GF_OK;
+    hipError_t e = hipMalloc((void**)&d_fr, sizeof(double) * 3 * per_chain * s->nchains);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain * s->nchains);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_rows, chain_bytes * s->nchains);
+    for (int g = 0; g < ngroups && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&ev[g], hipEventDisableTiming);
+    if (e == hipSuccess) rc = gf_internal_borrow_stream(device0, &copy_stream);
+    if (e == hipSuccess && rc == GF_OK) {
+        gf_internal_full_arbitration_grids(device0, stream, 1);      // see gf_sampler_postprocess_device
+        for (int ch = 0; ch < s->nchains && rc == GF_OK && e == hipSuccess; ++ch) {
+            gf_model* mc = models ? models[ch] : s->models ? s->models[ch] : s->model;
+            const double* d_theta = s->d_chain + (size_t)ch * s->nstore_cap * s->nwalkers * s->ndim;
+            rc = gf_model_propagate_on(mc, stream, d_theta, GF_LAYOUT_AOS, per_chain, d_fr + (size_t)ch * per_chain * 3,
+                                       d_st + (size_t)ch * per_chain);
+            if (rc == GF_OK)
+                e = gf_launch_join_rows(d_fr + (size_t)ch * per_chain * 3, d_st + (size_t)ch * per_chain, d_theta, s->ndim, per_chain,
+                                        d_rows + (size_t)ch * per_chain * width, s->cus, st);
+            if (rc == GF_OK && e == hipSuccess && ((ch + 1) % per_group == 0 || ch + 1 == s->nchains))
+                e = hipEventRecord(ev[ch / per_group], st);
+        }
+        gf_internal_full_arbitration_grids(device0, stream, 0);
+        for (int g = 0; g < ngroups && rc == GF_OK && e == hipSuccess; ++g) {
+            const int ch0 = g * per_group, ch1 = ch0 + per_group < s->nchains ? ch0 + per_group : s->nchains;
+            const size_t off = chain_bytes * (size_t)ch0, len = chain_bytes * (size_t)(ch1 - ch0);
+            (void)gf_host_prepare(reinterpret_cast<char*>(rows) + off, len);           // while the group is still being evaluated
+            e = hipEventSynchronize(ev[g]);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(reinterpret_cast<char*>(rows) + off, reinterpret_cast<const char*>(d_rows) + off, len,
+                                   hipMemcpyDeviceToHost, (hipStream_t)copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)copy_stream);
+        }
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    if (copy_stream) { (void)hipStreamSynchronize((hipStream_t)copy_stream); gf_internal_return_stream(device0, copy_stream); }
+    for (int g = 0; g < ngroups; ++g) if (ev[g]) (void)hipEventDestroy(ev[g]);
+    if (d_fr) (void)hipFree(d_fr);
+    if (d_st) (void)hipFree(d_st);
+    if (d_rows) (void)hipFree(d_rows);
+    if (rc != GF_OK) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess_rows");
     return GF_OK;
 }
 

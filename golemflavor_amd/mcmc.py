@@ -456,6 +456,20 @@ class DeviceEnsembleSampler:
             handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
         self._lib.check(self._L.gf_sampler_postprocess_rows_device(self._h, handles, d_rows), "gf_sampler_postprocess_rows_device")
 
+    def postprocess_rows(self, models=None):
+        """The same rows on the host, (nchains, nstored * nwalkers, 3 + ndim): the finished chains cross PCIe while the later
+        ones are still being post-processed."""
+        C = self._C
+        handles = None
+        if models is not None:
+            ms = [getattr(m, "model", m) for m in models]
+            handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
+        ns = int(self._L.gf_sampler_nstored(self._h))
+        out = np.empty((self.nchains, ns * self.k, 3 + self.dim))
+        self._lib.check(self._L.gf_sampler_postprocess_rows(self._h, handles, out.ctypes.data_as(self._lib._dp)),
+                        "gf_sampler_postprocess_rows")
+        return out
+
     def flat_steps(self):
         """The stored samples in the order the device holds them, (nsteps*nwalkers, ndim) [leading chain axis
         when nchains > 1]: `flatchain` without the transposition to emcee's walker-major order -- for

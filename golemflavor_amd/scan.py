@@ -213,6 +213,10 @@ class DeviceGather:
         first = jobs[order[0]]
         per = sampler.nstored * first.nwalkers                    # samples per grid point
         width = first.ndim if first.post_model is None else 3 + first.ndim
+        if self.rccl is None and self.world == 1 and first.post_model is not None:
+            # one rank: no exchange -- rows to the host group by group while the later chains are still post-processed
+            rows = sampler.postprocess_rows(models=[jobs[g].post_model for g in order])
+            return [rows[order.index(g)] for g in range(n_points)] if list(order) != list(range(n_points)) else list(rows)
         blk = slots * per * width * 8
         d_rows = self.m.alloc(blk)                                # ranks with fewer points leave the tail unused
         if first.post_model is None:

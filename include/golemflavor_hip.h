@@ -242,6 +242,10 @@ int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double
 /* the rows a scan saves, assembled on the device: d_rows [nchains][nstored][nwalkers][3 + ndim] = composition (NaN where the
  * reference would have raised) then the sample (scripts/mc_texture.py:216-223); synchronous */
 int gf_sampler_postprocess_rows_device(gf_sampler* s, gf_model* const* models, double* d_rows);
+/* the same rows in HOST memory, rows [nchains][nstored][nwalkers][3 + ndim]: the chains are post-processed one after the
+ * other and every finished group of chains crosses PCIe while the next ones are still being evaluated (what a one-rank scan
+ * hands to scripts/mc_texture.py's np.save); synchronous */
+int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* rows);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------------------- */
 /* Independent chains (grid points) shard across ranks with no data-path collective; the only

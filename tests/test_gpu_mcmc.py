@@ -144,6 +144,28 @@ def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
     assert a.shape == (3, 32 * 15, 9) and np.array_equal(a, b, equal_nan=True)
 
 
+def test_scan_rows_to_host_equal_rows_on_device():
+    """gf_sampler_postprocess_rows hands the scan's rows to the host group by group while later chains are still being
+    post-processed; they must be the rows gf_sampler_postprocess_rows_device assembles (19 chains: ragged last group)."""
+    from golemflavor_amd import scan
+    pts = scan.texture_grid(6)[:64:3][:19]
+    jobs = [scan._TexturePoint(p, g, dimension=6, texture=Texture.OEU, nwalkers=32, device=0) for g, p in enumerate(pts)]
+    s = mcmc_utils.DeviceEnsembleSampler(32, 6, [j.f for j in jobs], seed=4)
+    s.run_mcmc(np.stack([j.p0 for j in jobs]), 9)
+    models = [j.post_model for j in jobs]
+    host = s.postprocess_rows(models=models)
+    m0 = jobs[0].f.model
+    d_rows = m0.alloc(host.nbytes)
+    s.postprocess_rows_to_device(d_rows.ptr, models=models)
+    dev = d_rows.download(host.shape)
+    d_rows.free()
+    assert host.shape == (19, 9 * 32, 9) and np.array_equal(host, dev, equal_nan=True)
+    assert np.isnan(host[:, :, 0]).any() and np.isfinite(host[:, :, 0]).any()      # the grid reaches the failing region
+    s.close()
+    for j in jobs:
+        j.close()
+
+
 def test_grid_point_chain_does_not_depend_on_the_sharding():
     """Every chain of a stacked scan draws from the random stream of its GLOBAL grid index (gf_sampler_set_stream_ids):
     grid points 1 and 3 give bitwise the same chains whether their rank holds all four points (world 1) or just
