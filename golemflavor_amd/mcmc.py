@@ -520,12 +520,14 @@ def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident
     reference's scripts)."""
     if device_resident is None:
         device_resident = hasattr(getattr(ln_prob, "model", None), "_h")
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
     if device_resident:
-        if seed is None:
-            seed = int(np.random.randint(0, 2 ** 31 - 1))
         sampler = DeviceEnsembleSampler(nwalkers, ndim, ln_prob, seed=seed)
     else:
-        sampler = EnsembleSampler(nwalkers, ndim, ln_prob, threads=threads)
+        # (emcee seeds its RandomState from the OS; keyed by the global RNG instead, a host-driven run is as reproducible
+        # under np.random.seed as a device-resident one)
+        sampler = EnsembleSampler(nwalkers, ndim, ln_prob, threads=threads, seed=seed)
 
     print("Running burn-in")
     pos = p0
