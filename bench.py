@@ -22,11 +22,20 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant (only) kernel of th
 HIP events on the stream the kernel runs on.  `cpu_baseline` is the CPU oracle (oracle/, a
 long-double restatement of the reference, kind "port") timed on this host on a bounded sample.
 
-After the timed region (N = 1 only; `--no-extras` skips them) the other BASELINE configurations are measured too,
-each bounded to a few seconds, as sub-records of the same line: `c3` (1e7 Haar draws), `c4_bulk` / `c5_bulk` (the
-7- / 12-column flux-averaged posterior kernel with and without the unitarity status), `c4_scan` / `c5_scan` (the full
-64 x 2048 and 256 x 512 grid scans through the device sampler, by phase), `emcee_driven` (one 4096-walker ensemble)
-and `emcee_driven_c1_scaling` (100-walker chains, the metric's own wording, x {1, 16, 256, 4096}).
+After the timed region (`--no-extras` skips them) the other BASELINE configurations are measured too, each bounded to a
+few seconds, as sub-records of the same line.  At every N: `c4_scan_ref` / `c5_scan_ref` -- the full 64 x 2048 and
+256 x 512 grid scans SHARDED over the N ranks (grid point g -> rank g mod N, one stacked device sampler per rank) at the
+reference's own chain length (burnin 200 + 1000 stored steps, submitter/mc_texture_dag.py:33-39), chains gathered to rank 0
+over RCCL / xGMI (`gf_comm_gather`) and downloaded once, reported by phase (`rccl_init_s`, `sampling_s`, `pack_s`,
+`gather_bytes`, `gather_GBps`, `d2h_s`, `ranks`, `evals_per_s`; a fixed grid: these sub-records are STRONG scaling) -- and
+`cpu_baseline` (rank 0).  At N = 1 also: `c3` (1e7 Haar draws), `c4_bulk` / `c5_bulk` (the 7- / 12-column flux-averaged
+posterior kernel with and without the unitarity status), `c4_scan` / `c5_scan` (the same scans at 100 + 200 steps, the
+round-1/2 series), `emcee_driven` (one 4096-walker ensemble) and `emcee_driven_c1_scaling` (100-walker chains, the
+metric's own wording, x {1, 16, 256, 4096}).
+
+The line is put together by `assemble_line` / `scan_record_from_phases` from plain numbers, and the cross-rank reductions go
+through `reduce_step_timing` / `reduce_phases` on the control plane: tests/test_bench_line.py drives them with two ranks'
+synthetic measurements over the socket control plane on a box without a GPU.
 """
 import argparse
 import ctypes as C
@@ -53,6 +62,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 BYTES_PER_EVAL = 6 * 8 + 8     # 8*ndim read + 8 written, no fr / status blob
 SCLK_PEAK_GHZ = 2.4
 SETTLE_MS = 100.0                         # untimed steps before the warm-up, see main()
+REF_BURNIN, REF_NSTEPS = 200, 1000       # the reference's own chain length: submitter/mc_texture_dag.py:33-39
 FP64_ISSUE_PER_S = 256 * 4 * SCLK_PEAK_GHZ * 1e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one fp64 VALU instruction per 4 cycles at 2.4 GHz
 
 
@@ -67,6 +77,8 @@ def parse():
     ap.add_argument("--no-sampler", action="store_true", help="skip the emcee-driven extras (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3 / C4 / C5 sub-records (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="evaluations in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--scan-burnin", type=int, default=REF_BURNIN, help="burn-in steps of c4_scan_ref / c5_scan_ref")
+    ap.add_argument("--scan-nsteps", type=int, default=REF_NSTEPS, help="stored steps of c4_scan_ref / c5_scan_ref")
     return ap.parse_args()
 
 
@@ -232,32 +244,99 @@ def extra_bulk(device, ps, label, n=4 * 1024 * 1024):
     return out
 
 
-def extra_scan(device, config):
-    """C4 / C5 end to end at full size: stacked device sampler (100 burn-in + 200 stored steps), post-processing (C4),
-    chains to the host -- golemflavor_amd.scan's own code path on one rank."""
+def scan_setup(config, device):
+    """(grid points, walkers, point factory, evaluations per grid point as a function of (burnin, nsteps))."""
     from golemflavor_amd import scan
-    t0 = time.perf_counter()
     if config == "C4":
         pts = scan.texture_grid(6)
         nw = 2048
         make = lambda p, g: scan._TexturePoint(p, g, dimension=6, texture=Texture.OET, nwalkers=nw, device=device)  # noqa: E731
-        evals = nw * 300 + nw * 200
+        evals = lambda burnin, nsteps: nw * (burnin + nsteps) + nw * nsteps   # noqa: E731  chain + post-processing of the stored steps
     else:
         pts = scan.sens_grid()
         nw = 512
         make = lambda p, g: scan._SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
-        evals = nw * 300
-    stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
-    chains = scan.run_points(pts, list(range(len(pts))), make, 100, 200, stacked=True,
-                             gather=scan.DeviceGather(None, 0, 1, stage))
-    stage.close()
-    dt = time.perf_counter() - t0
+        evals = lambda burnin, nsteps: nw * (burnin + nsteps)                  # noqa: E731
+    return pts, nw, make, evals
+
+
+def reduce_phases(control, local):
+    """Per-phase seconds of one scan: the MAX over ranks (a phase ends when its slowest rank ends), byte counts: the SUM.
+    `local`: {name: number}; names ending in `_bytes` are summed.  Every rank calls it; the result is the same everywhere."""
+    keys = sorted(local)
+    parts = control.allgather_bytes(json.dumps({k: float(local[k]) for k in keys}).encode())
+    rows = [json.loads(x.decode()) for x in parts]
+    out = {}
+    for k in sorted({k for r in rows for k in r}):
+        vals = [r[k] for r in rows if k in r]
+        out[k] = float(sum(vals)) if k.endswith("_bytes") else float(max(vals))
+    return out
+
+
+def scan_record_from_phases(config, world, n_points, walkers, burnin, nsteps, evals_total, seconds, phases, *, gather_kind,
+                            rccl_init_s=None, chain_bytes_to_host=None, finite_fraction=None, nonunitary=None):
+    """One `c4_scan*` / `c5_scan*` sub-record from plain numbers (no GPU needed: tests/test_bench_line.py)."""
+    xgmi_s = phases.get("xgmi_s", 0.0)
+    gbytes = phases.get("gather_bytes", 0.0)
+    rec = {"workload": "%s: %d grid points x %d walkers, %d burn-in + %d stored steps, sharded over %d rank(s) (grid point g -> "
+                       "rank g mod N), one stacked device sampler per rank" % (config, n_points, walkers, burnin, nsteps, world),
+           "scaling": "strong (a fixed grid divided over the ranks)", "ranks": int(world), "grid_points": int(n_points),
+           "walkers": int(walkers), "burnin": int(burnin), "nsteps": int(nsteps), "seconds": float(seconds),
+           "evals": int(evals_total), "evals_per_s": evals_total / max(seconds, 1e-12),
+           "rccl_init_s": rccl_init_s, "setup_s": phases.get("setup"), "sampling_s": phases.get("sampling"),
+           "pack_s": phases.get("pack_s"), "xgmi_s": xgmi_s, "gather_bytes": int(gbytes),
+           "gather_GBps": (gbytes / xgmi_s / 1e9) if (xgmi_s and gbytes) else None,
+           "d2h_s": phases.get("d2h_s"), "gather": gather_kind,
+           "sampling_evals_per_s": n_points * walkers * (burnin + nsteps) / max(phases.get("sampling") or seconds, 1e-12),
+           "phases": {k: round(v, 4) for k, v in phases.items() if not k.endswith("_bytes")}}
+    if chain_bytes_to_host is not None:
+        rec["chain_bytes_to_host"] = int(chain_bytes_to_host)
+    if finite_fraction is not None:
+        rec["finite_fraction"] = float(finite_fraction)
+    if nonunitary is not None:
+        rec["nonunitary_proposals"] = nonunitary
+    return rec
+
+
+def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rccl=None, rccl_init_s=None):
+    """C4 / C5 end to end at full size, the grid sharded over the ranks: stacked device sampler, post-processing (C4), chains
+    gathered to rank 0 (RCCL / xGMI, then one download) -- golemflavor_amd.scan's own code path.  EVERY rank calls this;
+    rank 0 gets the record, the others None."""
+    from golemflavor_amd import scan
+    control = control or gdist.LocalBackend()
+    pts, nw, make, evals = scan_setup(config, device)
+    mine = gdist.shard(len(pts), rank, world)
+    control.barrier()
+    t0 = time.perf_counter()
+    chains, gather_kind, local = None, None, {}
+    if world == 1 or rccl is not None:
+        stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
+        g = scan.DeviceGather(rccl, rank, world, stage)
+        chains = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True, gather=g)
+        stage.close()
+        local = dict(scan.PHASES)
+        local.update({k: v for k, v in g.stats.items() if isinstance(v, (int, float)) and k not in ("ranks", "slots_per_rank")})
+        gather_kind = "rccl gather to rank 0 over xGMI (gf_comm_gather), one download" if rccl is not None else "device -> host (one rank)"
+    else:
+        # no communicator (reported in the line as rccl_error): the blocks go to rank 0 through the host control plane
+        loc = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True)
+        local = dict(scan.PHASES)
+        t1 = time.perf_counter()
+        chains = gdist.gather_chains_to_root(loc, len(pts), control)
+        local["host_gather_s"] = time.perf_counter() - t1
+        gather_kind = "host control plane (tcp) -- RCCL unavailable"
+    local["rank_seconds"] = time.perf_counter() - t0
+    control.barrier()
+    seconds = time.perf_counter() - t0                      # barrier to barrier: the slowest rank, the gather included
+    phases = reduce_phases(control, local)
+    seconds = float(control.allreduce_max([seconds])[0])
+    if rank != 0:
+        return None
     nbytes = sum(c.nbytes for c in chains)
-    return {"workload": "%s: %d grid points x %d walkers, 100 burn-in + 200 stored steps, one stacked sampler" % (config, len(pts), nw),
-            "grid_points": len(pts), "walkers": nw, "seconds": dt, "phases": {k: round(v, 4) for k, v in scan.PHASES.items()},
-            "evals": len(pts) * evals, "evals_per_s": len(pts) * evals / dt, "chain_bytes_to_host": nbytes,
-            "sampling_evals_per_s": len(pts) * nw * 300 / max(scan.PHASES.get("sampling", dt), 1e-9),
-            "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}
+    finite = float(np.mean([np.isfinite(c[:: max(1, len(c) // 4096)]).mean() for c in chains]))
+    return scan_record_from_phases(config, world, len(pts), nw, burnin, nsteps, len(pts) * evals(burnin, nsteps), seconds, phases,
+                                   gather_kind=gather_kind, rccl_init_s=rccl_init_s, chain_bytes_to_host=nbytes,
+                                   finite_fraction=finite, nonunitary=dict(scan.LAST_NONUNITARY) if scan.LAST_NONUNITARY else None)
 
 
 def extra_emcee(model, ps, walkers):
@@ -311,6 +390,77 @@ def extra_emcee(model, ps, walkers):
     return out
 
 
+def reduce_step_timing(control, elapsed, kernel_ms):
+    """The job's step time is the MAX over ranks (contract); so is the kernel's average launch duration."""
+    e, k = [float(x) for x in control.allreduce_max([elapsed, kernel_ms])]
+    return e, k
+
+
+def load_traffic(n):
+    """HBM traffic per launch: FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (they cannot be read inside
+    this run); the number is the one of the committed pass of this same command and batch size (profiles/traffic.json,
+    regenerated by profiles/run_profile.sh), None when that file is missing or does not match."""
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tp))
+        if int(tj.get("n", -1)) == n:
+            return tj.get("traffic_bytes_per_launch"), ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                        "of this command (not this run)")
+    except Exception:                      # noqa: BLE001
+        pass
+    return None, None
+
+
+def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_ms, control_plane, librccl, traffic=None,
+                  traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None):
+    """The ONE JSON line, from plain numbers (no GPU, no library: tests/test_bench_line.py).  `elapsed`, `kernel_ms`: already
+    reduced over the ranks (reduce_step_timing).  `extras`: sub-records by key.  `cpu`: the cpu_baseline record."""
+    n = walkers * ensembles
+    evals = float(n) * steps * world
+    value = evals / elapsed
+    ach = BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
+    metric = "walker-lnprob evals/sec (Gaussian llh, 100 walkers) at 1/2/4/8 MI355X"
+    try:                                   # BASELINE.json's own wording when the file travelled with the repo
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:                      # noqa: BLE001
+        pass
+    out = {
+        "metric": metric, "value": value, "unit": "evals/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "settle_ms_before_warmup": SETTLE_MS,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C2: examples/inference.ipynb 6-dim Gaussian-llh posterior, %d-walker ensembles, "
+                               "%d independent ensembles stacked per launch per GPU (theta resident in HBM)"
+                               % (walkers, ensembles),
+                   "walkers_per_ensemble": walkers, "ensembles_per_launch_per_gpu": ensembles,
+                   "evals_per_step_per_gpu": n, "ndim": 6, "parallelism": "independent ensembles sharded over %d GPU(s)" % world,
+                   "note": "BASELINE.json words the metric on its configs[0] (100-walker chain, CPU plumbing); the bench line "
+                           "is configs[1], 4096-walker ensembles on the GPU; the 100-walker chains themselves are in "
+                           "emcee_driven_c1_scaling; configs[3] and [4] (the sharded grid scans) are c4_scan_ref / c5_scan_ref"},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
+                     "kernel": "k_lnprob_sm_fast<6, SM_GAUSS, canonical, no fr>"},
+        "control_plane": control_plane, "librccl": librccl,
+    }
+    if rccl_init_s is not None:
+        out["rccl_init_s"] = rccl_init_s
+    if gathered_ok is not None:
+        out["rccl_gather_ok"] = gathered_ok
+    if rccl_error is not None:
+        out["rccl_error"] = rccl_error
+    for key, rec in (extras or {}).items():
+        out[key] = rec
+    if parity is not None:
+        out["parity_max_rel_vs_oracle"] = parity
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = value / cpu["value"]                          # vs the oracle port on this box's cores
+        refrate = cpu.get("reference_python_evals_per_s_1core_build_container")
+        if refrate:                                                         # vs the reference itself (timed where it can run)
+            out["gpu_over_reference_python_1core"] = value / refrate
+    return out
+
+
 def main():
     a = parse()
     json_out = _claim_stdout()
@@ -323,14 +473,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     L = _lib.lib()                           # libgolemhip.so (and with it /opt/rocm's runtime + librccl) before anything else ROCm
     control = gdist.SocketBackend(rank, world) if world > 1 else gdist.LocalBackend()
-    rccl, rccl_error, stuck = None, None, False
+    rccl, rccl_error, stuck, rccl_init_s = None, None, False, None
     ps, bf, desc = notebook_descriptor()
     if world > 1:
         # RCCL communicator of the library itself; its unique id travels over the socket control plane.  The timed
         # region has no collective, so an RCCL problem must not cost the measurement: the descriptor then goes over the
         # control plane, the failure is reported in the JSON line AND in the exit status.
+        t_r = time.perf_counter()
         rccl, rccl_error, stuck = gdist.open_rccl(rank, world, local_rank, control,
                                                   timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+        rccl_init_s = float(control.allreduce_max([time.perf_counter() - t_r])[0])
         # fixed physics constants: rank 0's packed descriptor is the one everybody uses
         desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if rccl is not None else control)[0]
 
@@ -368,94 +520,69 @@ def main():
     elapsed = time.perf_counter() - t0                 # ... at this instant; the MAX over ranks below is the job's time
     fence()                                            # closing bracket: barrier + synchronize (its latency is not a step)
     kernel_ms = ev0.elapsed_ms(ev1) / a.steps          # average launch duration on the kernel's stream
-    elapsed, kernel_ms = [float(x) for x in control.allreduce_max([elapsed, kernel_ms])]
+    elapsed, kernel_ms = reduce_step_timing(control, elapsed, kernel_ms)
 
-    # after the timed region: gather one chain block (the first ensemble's lnprob) from every rank over RCCL
+    # after the timed region: one chain block (the first ensemble's lnprob) from every rank to rank 0 over RCCL
     gathered_ok = None
     if rccl is not None:
         try:
             blk = 8 * a.walkers
-            d_all = model.alloc(blk * world)
-            rccl.allgather_device(d_out.ptr, d_all.ptr, blk)
-            allv = d_all.download((world, a.walkers))
-            mine = d_out.download((a.walkers,))
-            gathered_ok = bool(np.array_equal(allv[rank], mine, equal_nan=True))
+            d_all = model.alloc(blk * world) if rank == 0 else None
+            rccl.gather_device(d_out.ptr, d_all.ptr if rank == 0 else None, blk, 0)
+            gathered_ok = True
+            if rank == 0:
+                allv = d_all.download((world, a.walkers))
+                mine = d_out.download((a.walkers,))
+                gathered_ok = bool(np.array_equal(allv[0], mine, equal_nan=True) and np.all(np.isfinite(allv) | np.isinf(allv)))
         except Exception as exc:           # noqa: BLE001
             rccl_error = "%s: %s" % (type(exc).__name__, exc)
             gathered_ok = False
         oks = control.allgather_bytes(b"1" if gathered_ok else b"0")
         gathered_ok = all(x == b"1" for x in oks)
 
+    # sub-records.  The sharded scans run on EVERY rank (rank 0 assembles); the rest is rank 0's
+    extras = {}
+
+    def guarded(key, fn, collective=False):
+        try:
+            rec = fn()
+        except Exception as exc:           # noqa: BLE001
+            if collective and world > 1:
+                raise                      # a rank that left a collective half-way cannot be papered over
+            rec = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rec is not None:
+            extras[key] = rec
+
+    if world == 1 and rank == 0 and not a.no_sampler:
+        try:
+            extras.update(extra_emcee(model, ps, a.walkers))
+        except Exception as exc:           # noqa: BLE001
+            extras["emcee_driven"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if not a.no_extras:
+        if world == 1:
+            guarded("c3", lambda: extra_c3(local_rank))
+            guarded("c4_bulk", lambda: extra_bulk(local_rank, Cf.texture_paramset(6), "C4"))
+            guarded("c5_bulk", lambda: extra_bulk(local_rank, Cf.fr_paramsets(6, (0.4444, 0.0))[1], "C5"))
+            guarded("c4_scan", lambda: extra_scan(local_rank, "C4", 100, 200))
+            guarded("c5_scan", lambda: extra_scan(local_rank, "C5", 100, 200))
+        for key, cfg in (("c4_scan_ref", "C4"), ("c5_scan_ref", "C5")):
+            guarded(key, lambda cfg=cfg: extra_scan(local_rank, cfg, a.scan_burnin, a.scan_nsteps, rank, world, control, rccl,
+                                                    rccl_init_s), collective=True)
+
     if rank == 0:
-        evals = float(n) * a.steps * world
-        value = evals / elapsed
-        ach = BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (they cannot be read
-        # inside this run); the number below is the one of the committed pass of this same command and batch size
-        # (profiles/traffic.json, regenerated by profiles/run_profile.sh), null when that file does not match
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                if int(tj.get("n", -1)) == n:
-                    traffic = tj.get("traffic_bytes_per_launch")
-                    traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run)"
-            except Exception:
-                traffic = None
-        metric = "walker-lnprob evals/sec (Gaussian llh, 100 walkers) at 1/2/4/8 MI355X"
-        try:                                   # BASELINE.json's own wording when the file travelled with the repo
-            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-        except Exception:
-            pass
-        out = {
-            "metric": metric, "value": value, "unit": "evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_ms_before_warmup": SETTLE_MS,
-            "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: examples/inference.ipynb 6-dim Gaussian-llh posterior, %d-walker ensembles, "
-                                   "%d independent ensembles stacked per launch per GPU (theta resident in HBM)"
-                                   % (a.walkers, a.ensembles),
-                       "walkers_per_ensemble": a.walkers, "ensembles_per_launch_per_gpu": a.ensembles,
-                       "evals_per_step_per_gpu": n, "ndim": 6, "parallelism": "independent ensembles sharded over %d GPU(s)" % world,
-                       "note": "BASELINE.json words the metric on its configs[0] (100-walker chain, CPU plumbing); the bench line "
-                               "is configs[1], 4096-walker ensembles on the GPU; the 100-walker chains themselves are in "
-                               "emcee_driven_c1_scaling"},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
-                         "kernel": "k_lnprob_sm_fast<6, SM_GAUSS, canonical, no fr>"},
-            "control_plane": "tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
-            "librccl": gdist.rccl_library_info(),
-        }
-        if gathered_ok is not None:
-            out["rccl_gather_ok"] = gathered_ok
-        if rccl_error is not None:
-            out["rccl_error"] = rccl_error
-        if world == 1 and not a.no_sampler:
-            try:
-                out.update(extra_emcee(model, ps, a.walkers))
-            except Exception as exc:       # noqa: BLE001
-                out["emcee_driven"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if world == 1 and not a.no_extras:
-            for key, fn in (("c3", lambda: extra_c3(local_rank)),
-                            ("c4_bulk", lambda: extra_bulk(local_rank, Cf.texture_paramset(6), "C4")),
-                            ("c5_bulk", lambda: extra_bulk(local_rank, Cf.fr_paramsets(6, (0.4444, 0.0))[1], "C5")),
-                            ("c4_scan", lambda: extra_scan(local_rank, "C4")),
-                            ("c5_scan", lambda: extra_scan(local_rank, "C5"))):
-                try:
-                    out[key] = fn()
-                except Exception as exc:   # noqa: BLE001
-                    out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if world == 1 and not a.no_cpu_baseline:
+        cb, parity = None, None
+        if not a.no_cpu_baseline:
             cb, ref = cpu_baseline(ps, bf, theta, a.cpu_sample)
             got = d_out.download((len(ref),))
             with np.errstate(all="ignore"):
-                out["parity_max_rel_vs_oracle"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
-            out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = value / cb["value"]                       # vs the oracle port on this box's cores
-            refrate = cb.get("reference_python_evals_per_s_1core_build_container")
-            if refrate:                                                     # vs the reference itself (timed where it can run)
-                out["gpu_over_reference_python_1core"] = value / refrate
+                parity = float(np.max(np.abs(got - ref) / np.abs(ref)))
+        traffic, traffic_src = load_traffic(n)
+        out = assemble_line(world=world, steps=a.steps, warmup=a.warmup, walkers=a.walkers, ensembles=a.ensembles,
+                            elapsed=elapsed, kernel_ms=kernel_ms,
+                            control_plane="tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
+                            librccl=gdist.rccl_library_info(), traffic=traffic, traffic_src=traffic_src,
+                            gathered_ok=gathered_ok, rccl_error=rccl_error, rccl_init_s=rccl_init_s, extras=extras, cpu=cb,
+                            parity=parity)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 

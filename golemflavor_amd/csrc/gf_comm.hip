@@ -144,6 +144,41 @@ int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes
     return GF_OK;
 }
 
+// Gather to ONE rank: every rank's block lands in d_recv_on_root[rank * bytes_per_rank ...] on `root`; nobody else allocates
+// or receives `world x` the block.  This is what the reference's N jobs writing N files to one place amount to
+// (golemflavor/mcmc.py:108-126); an all-gather would put every chain of the scan on every GPU for nothing.  RCCL has no
+// ncclGather: one group of point-to-point operations -- the root posts world - 1 receives, every other rank one send, and
+// the root's own block is a device-to-device copy on the same stream.  xGMI is point to point, so the world - 1 transfers
+// run on world - 1 different links into the root.
+int gf_comm_gather(gf_comm* c, const void* d_send, void* d_recv_on_root, size_t bytes_per_rank, int root)
+{
+    if (!c || !d_send || root < 0 || root >= c->nranks) return GF_ERR_INVALID_ARG;
+    if (c->rank == root && !d_recv_on_root) return GF_ERR_INVALID_ARG;
+    if (bytes_per_rank == 0) return GF_OK;
+    GF_CHIP(hipSetDevice(c->device));
+    if (c->rank == root) {
+        char* dst = static_cast<char*>(d_recv_on_root);
+        hipError_t e = hipSuccess;
+        if (dst + (size_t)root * bytes_per_rank != d_send)
+            e = hipMemcpyAsync(dst + (size_t)root * bytes_per_rank, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream);
+        // the receives are posted whatever the local copy did: the peers are already inside their sends
+        ncclResult_t r = ncclSuccess;
+        if (c->nranks > 1) {
+            r = ncclGroupStart();
+            for (int p = 0; p < c->nranks && r == ncclSuccess; ++p)
+                if (p != root) r = ncclRecv(dst + (size_t)p * bytes_per_rank, bytes_per_rank, ncclChar, p, c->comm, c->stream);
+            const ncclResult_t r2 = ncclGroupEnd();
+            if (r == ncclSuccess) r = r2;
+        }
+        if (r != ncclSuccess) return comm_fail("ncclRecv (gather)", ncclGetErrorString(r));
+        if (e != hipSuccess) return comm_fail("gf_comm_gather", hipGetErrorString(e));
+    } else {
+        GF_NCCL(ncclSend(d_send, bytes_per_rank, ncclChar, root, c->comm, c->stream));
+    }
+    GF_CHIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
 int gf_comm_barrier(gf_comm* c)
 {
     if (!c) return GF_ERR_INVALID_ARG;

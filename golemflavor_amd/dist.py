@@ -53,6 +53,9 @@ class LocalBackend:
     def allgather_bytes(self, payload):
         return [bytes(payload)]
 
+    def gather_bytes(self, payload, root=0):
+        return [bytes(payload)]
+
     def allreduce_max(self, values):
         return np.asarray(values, dtype=np.float64).reshape(-1)
 
@@ -201,6 +204,20 @@ class SocketBackend:
             return bytes(buf)
         return self.allgather_bytes(bytes(buf) if self.rank == root else b"")[root]
 
+    def gather_bytes(self, payload, root=0):
+        """Every rank's payload, in rank order, on `root` only (None elsewhere): nothing is relayed back."""
+        payload = bytes(payload) if not isinstance(payload, (bytes, bytearray, memoryview)) else payload
+        if self.world == 1:
+            return [bytes(payload)]
+        if root != 0:                       # star topology: rank 0 is the hub
+            parts = self.allgather_bytes(payload)
+            return parts if self.rank == root else None
+        if self.rank == 0:
+            return [bytes(payload)] + [self._recv(self._peers[r]) for r in range(1, self.world)]
+        self._peers[0].sendall(struct.pack("<Q", len(payload)))
+        self._peers[0].sendall(payload)
+        return None
+
     def allgather(self, arr):
         a = np.ascontiguousarray(arr)
         parts = self.allgather_bytes(a.tobytes())
@@ -253,6 +270,11 @@ class GlooBackend:
         self._dist.all_gather_object(outs, bytes(payload))
         return outs
 
+    def gather_bytes(self, payload, root=0):
+        outs = [None] * self.world if self.rank == root else None
+        self._dist.gather_object(bytes(payload), outs, dst=root)
+        return outs
+
     def allreduce_max(self, values):
         return self.allgather(np.asarray(values, dtype=np.float64).reshape(-1)).max(axis=0)
 
@@ -266,21 +288,22 @@ class GlooBackend:
 class RcclBackend:
     """RCCL over xGMI via gf_comm_* (one communicator per process, bound to `device`).
 
-    `control`: the backend that ships rank 0's 128-byte unique id to the others (SocketBackend / GlooBackend), or a
-    callable `exchange_id(id_bytes_or_None) -> id_bytes`."""
+    `uid`: rank 0's 128-byte RCCL unique id, already shipped to this rank (`exchange_unique_id`).  For callers that hold
+    no id yet, `control` does the exchange here: the backend that ships it (SocketBackend / GlooBackend), or a callable
+    `exchange_id(id_bytes_or_None) -> id_bytes`."""
 
-    def __init__(self, rank, world, device, control=None):
+    def __init__(self, rank, world, device, control=None, uid=None):
         self._L = _lib.lib()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
-        uid = None
-        if self.rank == 0:
-            buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
-            _lib.check(self._L.gf_comm_unique_id(buf), "gf_comm_unique_id")
-            uid = bytes(buf)
-        if self.world > 1:
-            if control is None:
-                raise ValueError("RcclBackend needs a control backend to ship the unique id")
-            uid = control(uid) if callable(control) else control.broadcast_bytes(uid or b"", 0)
+        if uid is None:
+            if self.rank == 0:
+                uid = make_unique_id()
+            if self.world > 1:
+                if control is None:
+                    raise ValueError("RcclBackend needs a control backend to ship the unique id")
+                uid = control(uid) if callable(control) else control.broadcast_bytes(uid or b"", 0)
+        if uid is None or len(uid) != _lib.GF_COMM_ID_BYTES:
+            raise ValueError("RCCL unique id must be %d bytes, got %s" % (_lib.GF_COMM_ID_BYTES, None if uid is None else len(uid)))
         idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(uid)
         h = C.c_void_p()
         _lib.check(self._L.gf_comm_create(idb, self.rank, self.world, self.device, C.byref(h)), "gf_comm_create")
@@ -293,6 +316,11 @@ class RcclBackend:
 
     def allgather_device(self, d_send, d_recv, bytes_per_rank):
         _lib.check(self._L.gf_comm_allgather(self._h, d_send, d_recv, int(bytes_per_rank)), "gf_comm_allgather")
+
+    def gather_device(self, d_send, d_recv_on_root, bytes_per_rank, root=0):
+        """Rank r's block -> d_recv_on_root + r * bytes_per_rank on `root` (pass None elsewhere): only the root holds
+        world x the block (the reference: N jobs saving N files to one place, golemflavor/mcmc.py:108-126)."""
+        _lib.check(self._L.gf_comm_gather(self._h, d_send, d_recv_on_root, int(bytes_per_rank), int(root)), "gf_comm_gather")
 
     def allgather(self, arr, model):
         """Host array in, (world, ...) host array out, staged through `model`'s device buffers."""
@@ -321,17 +349,71 @@ def rccl_library_info():
     return buf.value.decode()
 
 
-def open_rccl(rank, world, device, control, timeout=120.0):
-    """An RcclBackend whose bootstrap cannot hang the job: the communicator is created in a helper thread with a
-    bounded wait, and (world > 1) all ranks agree over `control` whether everybody got one.
-    Returns (backend or None, error string or None, stuck) -- `stuck`: the helper thread never came back (the caller
-    must leave with os._exit after flushing its output: the thread would block interpreter shutdown)."""
+def make_unique_id():
+    """Rank 0's RCCL unique id (128 bytes)."""
+    buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
+    _lib.check(_lib.lib().gf_comm_unique_id(buf), "gf_comm_unique_id")
+    return bytes(buf)
+
+
+def exchange_unique_id(rank, world, control, make_id=make_unique_id, timeout=30.0):
+    """Rank 0's unique id on every rank, or (None, error text) on EVERY rank when rank 0 could not make one.
+
+    Runs in the caller's (main) thread and every rank always takes part, with the same two collectives in the same order
+    whatever happened on rank 0: the control plane stays in step.  Rank 0 sends the 128-byte id, or an EMPTY payload meaning
+    "no id" followed by its error text; a payload of any other length is refused on all ranks alike.  `make_id` itself is
+    bounded by `timeout` (a helper thread), so a hung ncclGetUniqueId cannot keep rank 0 out of the exchange."""
     import threading
+    uid, err = b"", ""
+    if rank == 0:
+        box = {}
+
+        def _make():
+            try:
+                box["uid"] = make_id()
+            except Exception as exc:           # noqa: BLE001
+                box["err"] = "%s: %s" % (type(exc).__name__, exc)
+
+        th = threading.Thread(target=_make, daemon=True)
+        th.start()
+        th.join(timeout=timeout)
+        if th.is_alive():
+            err = "timeout: RCCL unique id not available after %.0f s" % timeout
+        elif "err" in box:
+            err = box["err"]
+        else:
+            uid = bytes(box.get("uid") or b"")
+            if len(uid) != _lib.GF_COMM_ID_BYTES:
+                uid, err = b"", "unique id of %d bytes, expected %d" % (len(uid), _lib.GF_COMM_ID_BYTES)
+    if world > 1:
+        uid = control.broadcast_bytes(uid, 0)
+        err = control.broadcast_bytes(err.encode(), 0).decode()
+    if len(uid) != _lib.GF_COMM_ID_BYTES:
+        return None, err or "rank 0 sent %d bytes instead of a %d-byte unique id" % (len(uid), _lib.GF_COMM_ID_BYTES)
+    return uid, None
+
+
+def open_rccl(rank, world, device, control, timeout=120.0, make_id=make_unique_id, backend_factory=None):
+    """An RcclBackend whose bootstrap cannot hang the job or desynchronise the control plane.
+
+    1. `exchange_unique_id` in THIS thread: every rank takes part whatever rank 0's outcome (an empty payload means "no id":
+       all ranks then skip RCCL together).
+    2. only `gf_comm_create` (ncclCommInitRank) runs in a helper thread with a bounded wait -- it touches no socket.
+    3. (world > 1) all ranks agree over `control` whether everybody got a communicator.
+    Returns (backend or None, error string or None, stuck) -- `stuck`: the helper thread never came back (the caller
+    must leave with os._exit after flushing its output: the thread would block interpreter shutdown).
+    `make_id`, `backend_factory(rank, world, device, uid)`: injection points of the CPU tests."""
+    import threading
+    t0 = time.perf_counter()
+    uid, err = exchange_unique_id(rank, world, control, make_id=make_id, timeout=min(timeout, 30.0))
+    if uid is None:
+        return None, err, False
     box = {}
+    factory = backend_factory or (lambda r, w, d, u: RcclBackend(r, w, d, uid=u))
 
     def _setup():
         try:
-            box["b"] = RcclBackend(rank, world, device, control=control)
+            box["b"] = factory(rank, world, device, uid)
         except Exception as exc:           # noqa: BLE001
             box["err"] = "%s: %s" % (type(exc).__name__, exc)
 
@@ -341,7 +423,7 @@ def open_rccl(rank, world, device, control, timeout=120.0):
     stuck = th.is_alive()
     err = "timeout: RCCL communicator setup did not finish in %.0f s" % timeout if stuck else box.get("err")
     if world > 1:
-        # every rank reports, the stuck one too (its helper thread is past the id exchange, inside ncclCommInitRank):
+        # every rank reports, the stuck one too (its helper thread sits inside ncclCommInitRank and owns no socket):
         # nobody is left waiting in this exchange
         errs = control.allgather_bytes((err or "").encode())
         err = next((e.decode() for e in errs if e), None)
@@ -350,7 +432,12 @@ def open_rccl(rank, world, device, control, timeout=120.0):
         if b is not None:
             b.close()
         return None, err, stuck
-    return box["b"], None, False
+    b = box["b"]
+    try:
+        b.init_seconds = time.perf_counter() - t0
+    except Exception:                      # noqa: BLE001
+        pass
+    return b, None, False
 
 
 def broadcast_descriptors(descs, backend, root=0):
@@ -394,6 +481,40 @@ def gather_chains(local, n_points, backend, allgather=None):
         send[slot] = local[g]
     allb = ag(send)                                    # (world, slots, ...)
     return [np.array(allb[g % backend.world, g // backend.world]) for g in range(n_points)]
+
+
+def gather_chains_to_root(local, n_points, backend, root=0):
+    """The same blocks on `root` only (None elsewhere): each rank sends its own points once, nothing is relayed back -- the
+    host-side stand-in for `gf_comm_gather` when no RCCL communicator could be set up."""
+    mine = shard(n_points, backend.rank, backend.world)
+    if sorted(local) != mine:
+        raise ValueError("rank %d holds points %s, expected %s" % (backend.rank, sorted(local), mine))
+    if backend.world == 1:
+        return [np.asarray(local[g], dtype=np.float64) for g in range(n_points)]
+    blocks = [np.ascontiguousarray(local[g], dtype=np.float64) for g in mine]
+    shapes = {b.shape for b in blocks}
+    if len(shapes) > 1:
+        raise ValueError("chain blocks must share one shape, got %s" % shapes)
+    shp = np.zeros(8, dtype=np.int64)
+    if shapes:
+        s0 = next(iter(shapes))
+        shp[0] = len(s0)
+        shp[1:1 + len(s0)] = s0
+    payload = shp.tobytes() + b"".join(b.tobytes() for b in blocks)
+    parts = backend.gather_bytes(payload, root)
+    if backend.rank != root:
+        return None
+    out = [None] * n_points
+    for r, blob in enumerate(parts):
+        hdr = np.frombuffer(blob[:64], dtype=np.int64)
+        shape = tuple(int(x) for x in hdr[1:1 + int(hdr[0])])
+        pts = shard(n_points, r, backend.world)
+        if not pts:
+            continue
+        arr = np.frombuffer(blob, dtype=np.float64, offset=64).reshape((len(pts),) + shape)
+        for slot, g in enumerate(pts):
+            out[g] = arr[slot]
+    return out
 
 
 def run_grid(points, run_chain, backend):

@@ -4,7 +4,7 @@ posterior of scripts/fr.py / sens.py's scale scan), sharded over one process per
 The reference runs one HTCondor job per grid point (submitter/mc_texture_dag.py:57-71,
 submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`), and all grid points
 of a rank are stacked into ONE device-resident sampler -- one ensemble per posterior, one launch per
-half-step for all of them; chains are gathered at the end: RCCL all-gather (`gf_comm_allgather`)
+half-step for all of them; chains are gathered at the end: RCCL gather to rank 0 (`gf_comm_gather`)
 straight from the sampler's device chain buffer, one download on rank 0.  No collective on the data path.  The control
 plane (rendezvous, the RCCL id, barriers) is `dist.SocketBackend` -- no PyTorch in the process; any launcher that sets
 RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT works, torch.distributed.run included.
@@ -122,6 +122,7 @@ class _SensPoint:
 
 
 PHASES = {}          # wall-clock seconds of the last run_points call, by phase (reported by main)
+LAST_NONUNITARY = {}  # the last stacked run_points call: proposals the reference would have raised on, and how they were settled
 
 
 def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gather=None):
@@ -193,19 +194,34 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
 
 class DeviceGather:
     """The chain gather of a stacked scan on the device: every rank packs its chains (and, for mc_texture, their
-    post-processed compositions) into one device block of `slots` grid points, RCCL all-gathers the blocks over xGMI
-    (`rccl`: dist.RcclBackend; None with one rank), and rank 0 downloads the result once, into prefaulted memory."""
+    post-processed compositions) into one device block of `slots` grid points; RCCL gathers the blocks over xGMI onto
+    RANK 0 ONLY (`rccl`: dist.RcclBackend.gather_device -- one group of point-to-point transfers into the root; None with one
+    rank), and rank 0 downloads the result once, into prefaulted memory.  Only the root ever holds `world x` the block: the
+    reference's equivalent is N jobs saving N files to one place (golemflavor/mcmc.py:108-126).
 
-    def __init__(self, rccl, rank, world, model_for_buffers):
-        self.rccl, self.rank, self.world, self.m = rccl, rank, world, model_for_buffers
+    `stats` (after `run`): block bytes per rank, gathered bytes, seconds of the pack / xGMI / device-to-host phases."""
+
+    def __init__(self, rccl, rank, world, model_for_buffers, root=0):
+        self.rccl, self.rank, self.world, self.m, self.root = rccl, rank, world, model_for_buffers, root
+        self.stats = {}
 
     def _exchange(self, d_send, nbytes, shape, dtype):
         if self.rccl is None:
-            return d_send.download(shape[1:], dtype=dtype)[None] if self.rank == 0 else None
-        d_recv = self.m.alloc(nbytes * self.world)
-        self.rccl.allgather_device(d_send.ptr, d_recv.ptr, nbytes)
-        out = d_recv.download(shape, dtype=dtype) if self.rank == 0 else None
-        d_recv.free()
+            t0 = time.perf_counter()
+            out = d_send.download(shape[1:], dtype=dtype)[None] if self.rank == self.root else None
+            self.stats.update(xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0)
+            return out
+        is_root = self.rank == self.root
+        d_recv = self.m.alloc(nbytes * self.world) if is_root else None          # world x block on the root only
+        t0 = time.perf_counter()
+        self.rccl.gather_device(d_send.ptr, d_recv.ptr if is_root else None, nbytes, self.root)
+        t1 = time.perf_counter()
+        out = d_recv.download(shape, dtype=dtype) if is_root else None
+        t2 = time.perf_counter()
+        if is_root:
+            d_recv.free()
+        # bytes that crossed xGMI into the root: every block but its own
+        self.stats.update(xgmi_s=t1 - t0, d2h_s=t2 - t1, gather_bytes=int(nbytes) * (self.world - 1))
         return out
 
     def run(self, sampler, jobs, order, n_points):
@@ -213,19 +229,25 @@ class DeviceGather:
         first = jobs[order[0]]
         per = sampler.nstored * first.nwalkers                    # samples per grid point
         width = first.ndim if first.post_model is None else 3 + first.ndim
+        self.stats = {"ranks": self.world, "slots_per_rank": slots}
         if self.rccl is None and self.world == 1 and first.post_model is not None:
             # one rank: no exchange -- rows to the host group by group while the later chains are still post-processed
+            t0 = time.perf_counter()
             rows = sampler.postprocess_rows(models=[jobs[g].post_model for g in order])
+            self.stats.update(pack_s=0.0, xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0,
+                              block_bytes=int(rows.nbytes), note="post-processing and read-back overlap (one rank)")
             return [rows[order.index(g)] for g in range(n_points)] if list(order) != list(range(n_points)) else list(rows)
         blk = slots * per * width * 8
+        t0 = time.perf_counter()
         d_rows = self.m.alloc(blk)                                # ranks with fewer points leave the tail unused
         if first.post_model is None:
             sampler.chain_to_device(d_rows.ptr)
         else:                                                     # mc_texture.py:216-223 on the device: (fr, sample) rows
             sampler.postprocess_rows_to_device(d_rows.ptr, models=[jobs[g].post_model for g in order])
+        self.stats.update(pack_s=time.perf_counter() - t0, block_bytes=int(blk))
         rows = self._exchange(d_rows, blk, (self.world, slots, per, width), np.float64)
         d_rows.free()
-        if self.rank != 0:
+        if self.rank != self.root:
             return None
         return [rows[g % self.world, g // self.world] for g in range(n_points)]
 
@@ -305,7 +327,7 @@ def main(argv=None):
             mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
                           "nsteps": a.nsteps, "stacked": stacked,
-                          "gather": ("rccl device all-gather" if rccl is not None else "device -> host") if device_gather
+                          "gather": ("rccl device gather to rank 0" if rccl is not None else "device -> host") if device_gather
                           else ("socket control plane" if world > 1 else "local"),
                           "rccl_error": rccl_err, "librccl": gdist.rccl_library_info(),
                           "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 2
+#define GF_ABI_VERSION 3
 #define GF_MAX_DIM 16
 #define GF_MAX_BINS 64
 /* CP phases (dcp; the NP matrix's for texture NONE) must stay within +-GF_PHASE_MAX: range (sampled) or value
@@ -259,6 +259,10 @@ int gf_comm_create(const uint8_t id[GF_COMM_ID_BYTES], int rank, int nranks, int
 void gf_comm_destroy(gf_comm* c);
 int gf_comm_broadcast(gf_comm* c, void* host_buf, size_t bytes, int root);            /* host in/out   */
 int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank); /* device  */
+/* ABI 3.  Gather to one rank: rank r's block lands at d_recv_on_root + r * bytes_per_rank on `root` (NULL elsewhere); only the
+ * root holds nranks x the block.  Stands in for the reference's N jobs saving N chain files to one place
+ * (golemflavor/mcmc.py:108-126, submitter/mc_texture_dag.py:57-71): one ncclGroup of point-to-point transfers into the root. */
+int gf_comm_gather(gf_comm* c, const void* d_send, void* d_recv_on_root, size_t bytes_per_rank, int root);
 int gf_comm_barrier(gf_comm* c);
 const char* gf_comm_last_error(void);                 /* thread-local text of the last failing gf_comm_* call */
 int gf_comm_library_info(char* buf, size_t buflen);   /* "<ncclGetVersion code> <path of the loaded librccl>" */
