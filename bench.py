@@ -412,7 +412,8 @@ def load_traffic(n):
 
 
 def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_ms, control_plane, librccl, traffic=None,
-                  traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None):
+                  traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None,
+                  overrides=""):
     """The ONE JSON line, from plain numbers (no GPU, no library: tests/test_bench_line.py).  `elapsed`, `kernel_ms`: already
     reduced over the ranks (reduce_step_timing).  `extras`: sub-records by key.  `cpu`: the cpu_baseline record."""
     n = walkers * ensembles
@@ -441,6 +442,7 @@ def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_m
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL,
                      "kernel": "k_lnprob_sm_fast<6, SM_GAUSS, canonical, no fr>"},
         "control_plane": control_plane, "librccl": librccl,
+        "diagnostic_overrides": overrides,     # GF_* environment overrides the library honoured in this process ("" = none)
     }
     if rccl_init_s is not None:
         out["rccl_init_s"] = rccl_init_s
@@ -582,7 +584,7 @@ def main():
                             control_plane="tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
                             librccl=gdist.rccl_library_info(), traffic=traffic, traffic_src=traffic_src,
                             gathered_ok=gathered_ok, rccl_error=rccl_error, rccl_init_s=rccl_init_s, extras=extras, cpu=cb,
-                            parity=parity)
+                            parity=parity, overrides=_lib.diagnostic_overrides())
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 

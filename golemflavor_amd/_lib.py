@@ -15,7 +15,7 @@ GF_MAX_DIM = 16
 GF_MAX_BINS = 64
 GF_COMM_ID_BYTES = 128
 
-GF_OK, GF_ERR_INVALID_ARG, GF_ERR_NO_DEVICE, GF_ERR_HIP, GF_ERR_ALLOC, GF_ERR_COMM, GF_ERR_UNSUPPORTED = range(7)
+GF_OK, GF_ERR_INVALID_ARG, GF_ERR_NO_DEVICE, GF_ERR_HIP, GF_ERR_ALLOC, GF_ERR_COMM, GF_ERR_UNSUPPORTED, GF_ERR_QUEUE_OVERFLOW = range(8)
 GF_ST_OK, GF_ST_OUT_OF_PRIOR, GF_ST_NON_UNITARY, GF_ST_NAN = range(4)
 GF_MODE_PRIOR_ONLY, GF_MODE_SM_GAUSS, GF_MODE_BSM_GAUSS = range(3)
 GF_LAYOUT_AOS, GF_LAYOUT_SOA = range(2)
@@ -60,6 +60,8 @@ SIGNATURES = {
     "gf_strerror": (C.c_char_p, [C.c_int]),
     "gf_last_hip_error": (C.c_char_p, []),
     "gf_sizeof_model_desc": (C.c_size_t, []),
+    "gf_diagnostic_overrides": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "gf_device_trim": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "gf_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gf_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "gf_model_create": (C.c_int, [C.POINTER(GfModelDesc), C.c_int, C.POINTER(_vp)]),
@@ -152,6 +154,21 @@ def check(code, what=""):
             detail = L.gf_comm_last_error().decode()
         raise GolemHipError(code, "%s failed: %s%s" % (what or "libgolemhip call", msg,
                                                      (" [" + detail + "]") if detail else ""))
+
+
+def diagnostic_overrides():
+    """The GF_* environment overrides the library has honoured in this process ('' = none)."""
+    buf = C.create_string_buffer(1100)
+    check(lib().gf_diagnostic_overrides(buf, 1100), "gf_diagnostic_overrides")
+    return buf.value.decode()
+
+
+def device_trim(device=0):
+    """Release the device memory the library caches between uses (idle unitarity workspaces, pooled constant blocks);
+    returns the bytes handed back."""
+    n = C.c_size_t(0)
+    check(lib().gf_device_trim(int(device), C.byref(n)), "gf_device_trim")
+    return int(n.value)
 
 
 def device_count():

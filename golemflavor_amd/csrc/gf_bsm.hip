@@ -31,6 +31,8 @@
 #include <cstdlib>
 
 #include "gf_consts.h"
+
+extern "C" const char* gf_internal_env(const char* name, int affects_results);   // gf_capi.hip: getenv with a record
 #include "gf_launch.h"
 #include "gf_device.hpp"
 #include "gf_bsm_device.hpp"
@@ -59,6 +61,8 @@ __device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t
     unsigned int j = 0;
     for (unsigned long long mrest = amb; mrest != 0; mrest &= mrest - 1, ++j)
         if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)i * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
+        else uq->overflow = 1u;            // cannot happen while the host cuts batches to fit (gf_launch_bsm); if it ever does,
+                                           // the dropped pair's verdict is missing and the host call fails (GF_ERR_QUEUE_OVERFLOW)
 }
 
 // LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
@@ -227,8 +231,10 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
                     unsigned int base = 0;
                     if (lane == 0) base = atomicAdd(&wq->count, (unsigned int)npend);
                     base = (unsigned int)__shfl((int)base, 0);
-                    for (int j = lane; j < npend; j += GF_WAVE)
+                    for (int j = lane; j < npend; j += GF_WAVE) {
                         if (base + j < wq->cap) wq->items[base + j] = (unsigned long long)pend[wave][j];
+                        else wq->overflow = 1u;
+                    }
                     npend = 0;
                 }
             }
@@ -254,8 +260,10 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
         }
         __syncthreads();
         const unsigned int base = blk_base + blk_off[wave];
-        for (int j = lane; j < npend; j += GF_WAVE)
+        for (int j = lane; j < npend; j += GF_WAVE) {
             if (base + j < wq->cap) wq->items[base + j] = (unsigned long long)pend[wave][j];
+            else wq->overflow = 1u;
+        }
     }
 }
 
@@ -306,7 +314,7 @@ inline int grid_for(int64_t work_items, int per_block, int cus)
 inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 {
     (void)check;
-    const char* force = std::getenv("GF_BSM_LPW");                       // diagnostics / A-B
+    const char* force = gf_internal_env("GF_BSM_LPW", 0);                       // diagnostics / A-B
     if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
     if (nbins < 2) return 1;
     const int64_t simds = 4 * (int64_t)(cus > 0 ? cus : 256);
@@ -376,6 +384,9 @@ hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBs
     if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, nullptr, cus, s);
     int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
     if (wq && wq_cap < piece) piece = wq_cap;                            // ... and the walker queue of the deferred tier 2
+    // diagnostics only (needs GF_DIAGNOSTICS=1): pieces four times what the queues hold, to exercise the overflow report
+    static const bool overcommit = gf_internal_env("GF_DIAG_UQ_OVERCOMMIT", 1) != nullptr;
+    if (overcommit) piece *= 4;
     if (piece > 64) piece &= ~(int64_t)63;                               // whole tiles: every piece starts 16-B aligned like the batch
     if (piece < 1) piece = 1;
     if (layout != 0 && piece < n) return hipErrorInvalidValue;          // SoA columns cannot be cut: the caller sizes the queue for n

@@ -22,6 +22,8 @@
 
 static_assert(GF_MAX_DIM == 16 && GF_MAX_BINS == 64, "header / device constant mismatch");
 
+extern "C" const char* gf_internal_env(const char* name, int affects_results);
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -95,6 +97,13 @@ void split_matrix_ld(const cld u[3][3], double hi[18], double lo[18])
         }
     }
 }
+
+// Every environment override the library honours goes through gf_internal_env and is REMEMBERED: gf_diagnostic_overrides()
+// lists them, bench.py and scan.py print the list in their JSON line.  Overrides that can change a RESULT (the unitarity
+// tiers' thresholds: a verdict; GF_UNI_DUMP: fr[0]) are honoured only when GF_DIAGNOSTICS=1 is set as well, so that a stray
+// variable in somebody's shell cannot silently change what a run computes; ignoring one is reported once on stderr.
+std::mutex g_env_mu;
+char g_env_seen[1024] = "";
 
 bool finite_all(const double* p, int n)
 {
@@ -325,7 +334,7 @@ int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int6
     const int64_t nb = nbins > 0 ? nbins : 1;
     int64_t need = n * nb;
     int64_t max_items = UQ_MAX_ITEMS;
-    if (const char* e = std::getenv("GF_UQ_MAX_ITEMS")) {     // tests: a small queue, so that a modest batch is cut into pieces
+    if (const char* e = gf_internal_env("GF_UQ_MAX_ITEMS", 0)) {     // tests: a small queue, so that a modest batch is cut into pieces
         const long long v = std::atoll(e);
         if (v >= 65536 && v < UQ_MAX_ITEMS) max_items = v;
     }
@@ -339,6 +348,7 @@ int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int6
         GF_HIP(hipHostMalloc((void**)&w->h_seen, 64, hipHostMallocDefault));
         w->h_seen[0] = 0xffffffffu;              // nothing seen yet: the first launch takes the full grid
         w->h_seen[1] = 0;                        // host-only flag: full grids on request (gf_internal_full_arbitration_grids)
+        w->h_seen[2] = 0;                        // written by k_uni_resolve: a queue overflowed (check_queue_overflow)
     }
     int64_t cap = w->uq_cap ? w->uq_cap : 4096;
     while (cap < need) cap *= 2;
@@ -377,6 +387,23 @@ int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int6
     return GF_OK;
 }
 
+// Did an arbitration launch on this stream report a full queue?  Call after a stream synchronise (or ahead of new launches:
+// stale reports of earlier asynchronous launches).  The report is consumed.
+int check_queue_overflow(int device, hipStream_t st)
+{
+    UniWork* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool[device].work.find(st);
+        if (it != g_pool[device].work.end()) w = it->second;
+    }
+    if (!w || !w->h_seen) return GF_OK;
+    if (__atomic_exchange_n(&w->h_seen[2], 0u, __ATOMIC_RELAXED) == 0u) return GF_OK;
+    std::snprintf(g_err, sizeof(g_err), "a unitarity queue overflowed: (walker, bin) pairs were dropped and the status array of that batch is "
+                                        "incomplete (the host cuts batches to fit the queues: this is a library bug)");
+    return GF_ERR_QUEUE_OVERFLOW;
+}
+
 // One BSM launch with or without the verdict's workspace (the stream's, locked for the duration of the launches)
 int launch_bsm_on(gf_model* m, hipStream_t st, const double* d_theta, int layout, int64_t n, int with_llh, double* d_lnprob, double* d_fr,
                   int32_t* d_status, const char* what)
@@ -388,6 +415,8 @@ int launch_bsm_on(gf_model* m, hipStream_t st, const double* d_theta, int layout
     } else {
         UniWork* w = work_for(m->device, st);
         if (!w) return GF_ERR_ALLOC;
+        const int ro = check_queue_overflow(m->device, st);        // of an earlier asynchronous launch on this stream
+        if (ro != GF_OK) return ro;
         std::lock_guard<std::mutex> lk(w->mu);
         int64_t limit = 0;
         const int rq = ensure_uq(w, m->hb.nbins, st, layout, n, &limit);
@@ -451,6 +480,7 @@ const char* gf_strerror(int err)
     case GF_ERR_ALLOC: return "allocation failed";
     case GF_ERR_COMM: return "RCCL error";
     case GF_ERR_UNSUPPORTED: return "unsupported configuration";
+    case GF_ERR_QUEUE_OVERFLOW: return "unitarity queue overflow";
     default: return "unknown error";
     }
 }
@@ -461,6 +491,40 @@ const char* gf_last_hip_error(void) { return g_err; }
 void gf_internal_set_error(const char* msg) { std::snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
 
 size_t gf_sizeof_model_desc(void) { return sizeof(gf_model_desc); }
+
+// internal: getenv with a record.  `affects_results` != 0: honoured only under GF_DIAGNOSTICS=1.
+const char* gf_internal_env(const char* name, int affects_results)
+{
+    const char* v = std::getenv(name);
+    if (!v) return nullptr;
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    char item[160];
+    if (affects_results) {
+        const char* d = std::getenv("GF_DIAGNOSTICS");
+        if (!d || d[0] != '1') {
+            std::snprintf(item, sizeof(item), "%s(ignored)", name);
+            if (!std::strstr(g_env_seen, item)) {
+                std::fprintf(stderr, "libgolemhip: %s is set but GF_DIAGNOSTICS=1 is not: ignored (it would change results)\n", name);
+                if (std::strlen(g_env_seen) + std::strlen(item) + 2 < sizeof(g_env_seen)) { if (g_env_seen[0]) std::strcat(g_env_seen, " "); std::strcat(g_env_seen, item); }
+            }
+            return nullptr;
+        }
+    }
+    std::snprintf(item, sizeof(item), "%s=%.100s", name, v);
+    if (!std::strstr(g_env_seen, item) && std::strlen(g_env_seen) + std::strlen(item) + 2 < sizeof(g_env_seen)) {
+        if (g_env_seen[0]) std::strcat(g_env_seen, " ");
+        std::strcat(g_env_seen, item);
+    }
+    return v;
+}
+
+int gf_diagnostic_overrides(char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return GF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    std::snprintf(buf, buflen, "%s", g_env_seen);
+    return GF_OK;
+}
 
 int gf_device_count(int* count)
 {
@@ -625,16 +689,16 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
             double lo_dec = 2.7, hi_dec = 2.6, lo_nl_dec = 4.6;
             b.uni_a_ok = 2e-11;
             b.uni_a_lin = 1e-16;
-            if (const char* e = std::getenv("GF_UNI_BAND_DECADES")) {
+            if (const char* e = gf_internal_env("GF_UNI_BAND_DECADES", 1)) {
                 const double v = std::atof(e);
                 if (v >= 0.0 && v <= 12.0) { lo_dec = hi_dec = lo_nl_dec = v; if (v == 0.0) b.uni_a_lin = 0.0; }
             }
             b.uni_lo = 1e-7 * 2048.0 * std::pow(10.0, -lo_dec);
             b.uni_hi = 1e-7 * 2048.0 * std::pow(10.0, hi_dec);
             b.uni_lo_nl = 1e-7 * 2048.0 * std::pow(10.0, -lo_nl_dec);
-            if (std::getenv("GF_UNI_NO_WEIGHT_GATE")) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
-            if (const char* e = std::getenv("GF_UNI_A_OK")) b.uni_a_ok = std::atof(e);  // diagnostics: tier 1's threshold
-            if (std::getenv("GF_UNI_DUMP")) { b.uni_lo = b.uni_lo_nl = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the estimate
+            if (gf_internal_env("GF_UNI_NO_WEIGHT_GATE", 1)) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
+            if (const char* e = gf_internal_env("GF_UNI_A_OK", 1)) b.uni_a_ok = std::atof(e);  // diagnostics: tier 1's threshold
+            if (gf_internal_env("GF_UNI_DUMP", 1)) { b.uni_lo = b.uni_lo_nl = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the estimate
         }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order
         {
@@ -767,6 +831,7 @@ void gf_internal_full_arbitration_grids(int device, void* stream, int on)
     if (!w->h_seen) {
         if (hipHostMalloc((void**)&w->h_seen, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w->h_seen = nullptr; return; }
         w->h_seen[0] = 0xffffffffu;
+        w->h_seen[2] = 0;
     }
     w->h_seen[1] = on ? 1u : 0u;
 }
@@ -841,7 +906,7 @@ static int run_host_pipelined(gf_model* m, const double* theta, int64_t n, doubl
     }
     GF_HIP(hipEventSynchronize(m->ev_down[(nchunks - 1) & 1]));
     copy_out(nchunks - 1);
-    return GF_OK;
+    return status ? check_queue_overflow(m->device, m->stream) : GF_OK;
 }
 
 static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status,
@@ -853,7 +918,7 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     std::lock_guard<std::mutex> lk(m->call_mu);
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
-    static const bool pipe_off = std::getenv("GF_NO_HOST_PIPELINE") != nullptr;  // diagnostics / A-B
+    static const bool pipe_off = gf_internal_env("GF_NO_HOST_PIPELINE", 0) != nullptr;  // diagnostics / A-B
     if (n >= PIPE_MIN_ROWS && !pipe_off) return run_host_pipelined(m, theta, n, lnprob, fr, status, with_llh);
     int rc = ensure_staging(m, n, n);
     if (rc != GF_OK) return rc;
@@ -866,7 +931,7 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     // Small batches (emcee's half-ensemble of a 100-walker chain is 50 rows): the kernel reads theta from and
     // writes its results to the pinned, device-mapped staging buffer directly -- one launch and one stream
     // sync instead of launch + two DMA transfers, each of which costs more than the kilobytes they move.
-    static const bool zc_off = std::getenv("GF_NO_ZEROCOPY") != nullptr;       // diagnostics / A-B
+    static const bool zc_off = gf_internal_env("GF_NO_ZEROCOPY", 0) != nullptr;       // diagnostics / A-B
     if (n <= GF_ZEROCOPY_MAX_ROWS && !zc_off) {
         if (with_llh)
             rc = launch_lnprob(m, m->stream, h_theta, GF_LAYOUT_AOS, n, h_out, fr ? h_fr : nullptr, status ? h_st : nullptr);
@@ -877,7 +942,7 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
         if (with_llh) std::memcpy(lnprob, h_out, sizeof(double) * n);
         if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
         if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
-        return GF_OK;
+        return status ? check_queue_overflow(m->device, m->stream) : GF_OK;
     }
     GF_HIP(hipMemcpyAsync(m->d_theta, h_theta, sizeof(double) * nd * n, hipMemcpyHostToDevice, m->stream));
     double* d_ln = m->d_out;
@@ -894,7 +959,7 @@ static int run_host(gf_model* m, const double* theta, int64_t n, double* lnprob,
     if (with_llh) std::memcpy(lnprob, h_out, sizeof(double) * n);
     if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
     if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
-    return GF_OK;
+    return status ? check_queue_overflow(m->device, m->stream) : GF_OK;
 }
 
 int gf_lnprob_batch(gf_model* m, const double* theta, int64_t n, double* lnprob, double* fr, int32_t* status)
@@ -947,7 +1012,7 @@ int gf_lnprob_cube_batch(gf_model* m, const double* cube, int64_t n, int nscan, 
     std::memcpy(lnprob, h_out, sizeof(double) * n);
     if (fr) std::memcpy(fr, h_fr, sizeof(double) * 3 * n);
     if (status) std::memcpy(status, h_st, sizeof(int32_t) * n);
-    return GF_OK;
+    return status ? check_queue_overflow(m->device, m->stream) : GF_OK;
 }
 
 int gf_propagate_batch(gf_model* m, const double* theta, int64_t n, double* fr, int32_t* status)
@@ -1019,7 +1084,7 @@ int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes
     // 8 ms per GiB -- so a helper thread maps chunk k + 1 while chunk k crosses PCIe.  (One byte per page is written ahead of
     // the copy that overwrites the page anyway.)
     constexpr size_t D2H_PIPE_MIN = (size_t)256 << 20, D2H_CHUNK = (size_t)128 << 20;
-    static const bool pipe_off = std::getenv("GF_NO_D2H_PIPELINE") != nullptr;            // diagnostics / A-B
+    static const bool pipe_off = gf_internal_env("GF_NO_D2H_PIPELINE", 0) != nullptr;            // diagnostics / A-B
     if (bytes < D2H_PIPE_MIN || pipe_off) {
         GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
         GF_HIP(hipStreamSynchronize(m->stream));
@@ -1162,7 +1227,55 @@ int gf_host_prepare(void* buf, size_t bytes)
 int gf_model_sync(gf_model* m)
 {
     if (!m) return GF_ERR_INVALID_ARG;
-    if (m->stream) GF_HIP(hipStreamSynchronize(m->stream));     // no stream yet: nothing was ever enqueued
+    if (!m->stream) return GF_OK;                               // no stream yet: nothing was ever enqueued
+    GF_HIP(hipStreamSynchronize(m->stream));
+    return check_queue_overflow(m->device, m->stream);          // of the *_device launches this call waited for
+}
+
+// internal (gf_sampler.hip): the same report for launches the sampler put on `stream` and has just synchronised
+int gf_internal_check_overflow(int device, void* stream)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES) return GF_ERR_INVALID_ARG;
+    return check_queue_overflow(device, (hipStream_t)stream);
+}
+
+// Release what the library keeps cached on `device` between uses: the unitarity workspaces (arbitration queue, walker queue,
+// side buffer: up to 8 GiB in all) of pooled, idle streams, and the pooled constant blocks.  Streams in use keep theirs.
+// *released_bytes (may be NULL): device memory handed back.  For long-lived processes that ran one large scan and go on
+// with small work.
+int gf_device_trim(int device, size_t* released_bytes)
+{
+    int cus = 0;
+    const int rc = pool_device(device, &cus);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipSetDevice(device));
+    // the idle streams leave the pool while their workspaces are released (nobody can pick one up half-way) and return after
+    std::vector<hipStream_t> streams;
+    std::vector<UniWork*> idle;
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        streams.swap(dp.streams);
+        for (hipStream_t st : streams) {
+            auto it = dp.work.find(st);
+            if (it != dp.work.end() && it->second) idle.push_back(it->second);
+        }
+        blocks.swap(dp.blocks);
+    }
+    size_t total = 0;
+    for (UniWork* w : idle) {
+        std::lock_guard<std::mutex> lk(w->mu);
+        total += w->bytes();
+        w->release();
+    }
+    for (void* b : blocks) { (void)hipFree(b); total += CONST_BLOCK_BYTES; }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        for (hipStream_t st : streams) dp.streams.push_back(st);
+    }
+    if (released_bytes) *released_bytes = total;
     return GF_OK;
 }
 

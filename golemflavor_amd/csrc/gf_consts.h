@@ -77,6 +77,6 @@ struct GfUniQueue {
     unsigned int count;             // items pushed by the evaluation kernel of the current launch
     unsigned int done;              // blocks of the resolve kernel that have finished (the last one resets both)
     unsigned int cap;               // capacity of items[]
-    unsigned int pad_;
+    unsigned int overflow;          // set by a producer that found the queue full (its item was DROPPED); k_uni_resolve reports it to the host and clears it
     unsigned long long items[1];    // [cap]
 };

@@ -17,6 +17,8 @@
 #include <cstdlib>
 
 #include "gf_consts.h"
+
+extern "C" const char* gf_internal_env(const char* name, int affects_results);   // gf_capi.hip: getenv with a record
 #include "gf_launch.h"
 
 #include "gf_device.hpp"
@@ -394,7 +396,7 @@ hipError_t launch_lnprob_sm_nm(const GfCommon& c, const double* ptab, const doub
         if (n <= 2048 && n % GF_WAVE != 0) nfull = 0;
         if (layout == 0 && nfull > 0) {
 #ifdef GF_EXPERIMENTAL_RING
-            static const bool use_ring = std::getenv("GF_SM_RING") != nullptr;
+            static const bool use_ring = gf_internal_env("GF_SM_RING", 0) != nullptr;
 #else
             constexpr bool use_ring = false;
 #endif

@@ -23,6 +23,8 @@
 
 #include "../../include/golemflavor_hip.h"
 #include "gf_consts.h"
+
+extern "C" const char* gf_internal_env(const char* name, int affects_results);   // gf_capi.hip: getenv with a record
 #include "gf_device.hpp"
 #include "gf_bsm_device.hpp"
 #include "gf_launch.h"
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch_multi(const StretchArgs
 inline int lanes_per_walker(int mode, int64_t walkers, int nbins_max, int cus)
 {
     if (mode != MODE_BSM_GAUSS || nbins_max < 2) return 1;
-    const char* force = std::getenv("GF_SAMPLER_LPW");                 // diagnostics / A-B, read per run
+    const char* force = gf_internal_env("GF_SAMPLER_LPW", 0);                 // diagnostics / A-B, read per run
     if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
     const int64_t want = (int64_t)cus * 4 * 4;
     for (int lpw : {1, 4, 16}) {
@@ -531,6 +533,7 @@ int gf_internal_borrow_stream(int device, void** stream);
 void gf_internal_return_stream(int device, void* stream);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
                           int32_t* d_status);
+int gf_internal_check_overflow(int device, void* stream);
 }
 
 namespace {
@@ -800,7 +803,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         int threads = 0;
         size_t lds = 0;
         persist_geometry(s->nwalkers, s->ndim, &threads, &lds);
-        const char* env = std::getenv("GF_SAMPLER_PERSIST");          // "0": always the per-half-step grid kernels
+        const char* env = gf_internal_env("GF_SAMPLER_PERSIST", 0);          // "0": always the per-half-step grid kernels
         if (c->mode != MODE_BSM_GAUSS && lds > 0 && !(env && env[0] == '0')) {
             PersistArgs pa;
             pa.commons = s->d_commons; pa.ptabs = s->d_ptabs; pa.nmodels = s->models ? s->nchains : 1;
@@ -834,7 +837,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     }
     constexpr int GRAPH_STEPS = 16;
     int64_t done = 0;
-    const bool no_graph = std::getenv("GF_SAMPLER_NO_GRAPH") != nullptr;          // diagnostics, read per run
+    const bool no_graph = gf_internal_env("GF_SAMPLER_NO_GRAPH", 0) != nullptr;          // diagnostics, read per run
     if (!no_graph && nsteps >= 2 * GRAPH_STEPS) {
         // launch-bound inner loop -> hipGraph: capture GRAPH_STEPS steps once, replay
         if (!s->graph || s->graph_chain != a.chain || s->graph_lnp_chain != a.lnp_chain || s->graph_cap != a.nstore_cap ||
@@ -1048,6 +1051,7 @@ int gf_sampler_postprocess_device(gf_sampler* s, gf_model* const* models, double
     }
     gf_internal_full_arbitration_grids(device0, stream, 0);
     GFS_HIP(hipStreamSynchronize(st));
+    if (rc == GF_OK && d_status) rc = gf_internal_check_overflow(device0, stream);
     return rc;
 }
 
@@ -1153,7 +1157,7 @@ int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* 
     if (rc != GF_OK) return rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess_rows");
-    return GF_OK;
+    return gf_internal_check_overflow(device0, stream);
 }
 
 int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* fr, int32_t* status, int nbins,
@@ -1207,7 +1211,7 @@ int gf_sampler_postprocess_with(gf_sampler* s, gf_model* const* models, double* 
     if (d_c) (void)hipFree(d_c);
     if (rc != GF_OK) return rc;
     if (e != hipSuccess) return sfail(e, "gf_sampler_postprocess");
-    return GF_OK;
+    return status ? gf_internal_check_overflow(device0, stream) : GF_OK;
 }
 
 }  // extern "C"

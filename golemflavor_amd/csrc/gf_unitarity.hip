@@ -17,6 +17,8 @@
 #include <cstdlib>
 
 #include "gf_consts.h"
+
+extern "C" const char* gf_internal_env(const char* name, int affects_results);   // gf_capi.hip: getenv with a record
 #include "gf_launch.h"
 #include "gf_x87.hpp"
 
@@ -93,12 +95,20 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&uq->done, 1u) == gridDim.x - 1) {
+            // a producer found one of the queues full and dropped an item: the verdicts of this launch are incomplete
+            const bool ov = uq->overflow != 0u || uq->count > uq->cap || (wq && (wq->overflow != 0u || wq->count > wq->cap));
             uq->count = 0;
             uq->done = 0;
-            if (wq) wq->count = 0;                                      // k_bsm_tier2's walker queue: it ran before this kernel
+            uq->overflow = 0;
+            if (wq) { wq->count = 0; wq->overflow = 0; }                // k_bsm_tier2's walker queue: it ran before this kernel
             __threadfence();
-            // what this launch found, in host memory: sizes the grid of the next one (gf_launch_uni_resolve)
-            if (seen) { __atomic_store_n(seen, count, __ATOMIC_RELAXED); __threadfence_system(); }
+            // what this launch found, in host memory: sizes the grid of the next one (gf_launch_uni_resolve); seen[2]: sticky
+            // overflow report, read and cleared by the host (gf_capi.hip: check_queue_overflow)
+            if (seen) {
+                __atomic_store_n(seen, count, __ATOMIC_RELAXED);
+                if (ov) __atomic_store_n(seen + 2, 1u, __ATOMIC_RELAXED);
+                __threadfence_system();
+            }
         }
     }
 }
@@ -129,7 +139,7 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
     // are the call, get 64 blocks, and batches whose evaluation takes longer than that anyway one block per CU.
     const int64_t floor_blocks = max_items >= 65536 * 16 ? cus : 64;
     if (blocks < floor_blocks) blocks = floor_blocks;
-    static const int forced = [] { const char* e = std::getenv("GF_UNI_RESOLVE_BLOCKS"); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
+    static const int forced = [] { const char* e = gf_internal_env("GF_UNI_RESOLVE_BLOCKS", 0); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
     if (forced > 0) blocks = forced;
     hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);
     return hipGetLastError();

@@ -45,7 +45,7 @@ def log_gauss_mass(a, b):
 def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=-320.0,
                   source_ratio=(1.0, 2.0, 0.0), texture=Texture.NONE, dimension=3, binning=None,
                   spectral_index=-2.0, flat_llh=1.0, scale_fixed=None, mm_fixed=None,
-                  sm_fixed=None, src_columns=None):
+                  sm_fixed=None, src_columns=None, no_bsm=False):
     """Flatten a posterior definition into a `GfModelDesc`.
 
     llh_paramset : ParamSet whose order is the column order of theta.
@@ -60,6 +60,14 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     mm_fixed     : the four NP mixing parameters of Texture.NONE when they are not sampled (the tuple
                    params_to_BSMu takes directly, fr.py:354-358,378).
 
+    no_bsm       : args.no_bsm of the flux-averaged posterior (fr.py:437-438): no new-physics term at all.  The
+                   reference's branch cannot run (it hands u_to_fr a 2-D source flux, an einsum subscript mismatch:
+                   SURVEY App. C-2); it is defined here as what it evidently means, u_to_fr(source_ratio, sm_u) -- the
+                   standard propagation with the mixing angles taken from theta under the flux average's own rule
+                   (all six oscillation parameters scanned, else NuFIT: fr.py:425-435) and the source fixed.  The
+                   posterior then runs through the SM kernels (no energy bins, no unitarity test: nothing is
+                   diagonalised).  Parity unpinned: there is no reference output to compare with.
+
     A single SRCANGLES-tagged column is scripts/mc_x.py's `astroX` (mc_x.py:41-44): the source composition is
     normalize_fr((x, 1 - x, 0)) of that column (mc_x.py:186-190).
     """
@@ -71,6 +79,11 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     d.abi_version = _lib.GF_ABI_VERSION
     d.ndim = ndim
     d.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+    bsm_rules = d.mode == _lib.GF_MODE_BSM_GAUSS               # column rules of flux_averaged_BSMu (fr.py:420-435)
+    if no_bsm:
+        if not bsm_rules:
+            raise ValueError("no_bsm only applies to the flux-averaged (BSM_GAUSS) posterior")
+        d.mode = _lib.GF_MODE_SM_GAUSS
     d.texture = Texture(texture).value if not isinstance(texture, Texture) else texture.value
     d.dimension = int(dimension)
     names = [p.name for p in params]
@@ -93,7 +106,7 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
     def col(name):
         return names.index(name) if name in names else -1
 
-    if d.mode == _lib.GF_MODE_BSM_GAUSS:
+    if bsm_rules:
         # fr.py:422-435: mixing angles and mass splittings come from theta only if all six are scanned
         scanned = set(SM_NAMES + MASS_NAMES).issubset(names)
         sm_idx = [col(n) if scanned else -1 for n in SM_NAMES]
@@ -112,6 +125,8 @@ def compile_model(llh_paramset, mode, *, bestfit_fr=None, smearing=None, offset=
         d.mass_fixed[k] = MASS_EIGENVALUES[k]
 
     src_idx = [i for i, p in enumerate(params) if p.tag is ParamTag.SRCANGLES]
+    if bsm_rules:
+        src_idx = []                                           # the flux average propagates args.source_ratio (fr.py:416-419)
     if src_columns is not None:
         src_idx = [int(x) for x in src_columns]
     d.idx_src_x = -1

@@ -69,12 +69,14 @@ def flux_averaged_BSMu(theta, args, spectral_index, llh_paramset):
     """golemflavor/fr.py:403-458, same name and signature, evaluated on the device: the flux-averaged measured
     composition for theta (ndim,) -> (3,) or (n, ndim) -> (n, 3).  `spectral_index` cancels in u_to_fr
     (fr.py:535 divides by the summed source flux) and is accepted for signature compatibility.
-    Raises AssertionError('Matrix is not unitary!') where the reference's test_unitarity would (fr.py:493-498)."""
+    Raises AssertionError('Matrix is not unitary!') where the reference's test_unitarity would (fr.py:493-498).
+    `args.no_bsm` (fr.py:437-438): u_to_fr(source_ratio, sm_u), see descriptor.compile_model."""
     from . import _lib
     from .descriptor import compile_model
     from .model import Model
     desc = compile_model(llh_paramset, "BSM_GAUSS", bestfit_fr=(1 / 3,) * 3, smearing=0.02, source_ratio=args.source_ratio,
-                         texture=args.texture, dimension=args.dimension, binning=args.binning)
+                         texture=args.texture, dimension=args.dimension, binning=args.binning,
+                         no_bsm=bool(getattr(args, "no_bsm", False)))
     with Model(desc, device=int(getattr(args, "device", 0))) as m:
         frs, st = m.propagate(theta)
     if np.any(st == _lib.GF_ST_NON_UNITARY):

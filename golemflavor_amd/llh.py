@@ -79,11 +79,12 @@ def bsm_ln_prob(args, asimov_paramset, llh_paramset, smearing=0.02, device=0, **
     """golemflavor/llh.py:121-130 `ln_prob(theta, args, asimov_paramset, llh_paramset)` with the
     GolemFit likelihood replaced by the Gaussian substitute the README sanctions
     (README.md:70-74): multi_gaussian(measured, angles_to_fr(asimov BESTFIT angles), smearing).
-    `args` needs: source_ratio, dimension, texture, binning (edges)."""
+    `args` needs: source_ratio, dimension, texture, binning (edges); `args.no_bsm` (fr.py:437-438) is honoured:
+    the posterior is then lnprior + the Gaussian around u_to_fr(source_ratio, sm_u) (descriptor.compile_model)."""
     bf = fr_utils.angles_to_fr(asimov_paramset.from_tag(ParamTag.BESTFIT, values=True))
     desc = compile_model(llh_paramset, "BSM_GAUSS", bestfit_fr=bf, smearing=smearing,
                          source_ratio=args.source_ratio, texture=args.texture,
-                         dimension=args.dimension, binning=args.binning)
+                         dimension=args.dimension, binning=args.binning, no_bsm=bool(getattr(args, "no_bsm", False)))
     return LnProb(desc, device=device, **kw)
 
 
@@ -117,7 +118,7 @@ def _fingerprint(args, asimov_paramset, llh_paramset, smearing):
     bf = tuple(float(x) for x in asimov_paramset.from_tag(ParamTag.BESTFIT, values=True))
     tex = args.texture.value if hasattr(args.texture, "value") else int(args.texture)
     return (ps, bf, tuple(float(x) for x in np.ravel(args.source_ratio)), int(args.dimension), tex,
-            tuple(float(x) for x in np.ravel(args.binning)), float(smearing))
+            tuple(float(x) for x in np.ravel(args.binning)), float(smearing), bool(getattr(args, "no_bsm", False)))
 
 
 def _bound(args, asimov_paramset, llh_paramset):

@@ -553,6 +553,42 @@ def mcmc(p0, ln_prob, ndim, nwalkers, burnin, nsteps, threads=1, device_resident
     return samples
 
 
+def _flag(text):
+    """'True' / 'False' command-line values (the reference's misc.parse_bool)."""
+    t = str(text).strip().lower()
+    if t in ("true", "t", "1", "yes", "y"):
+        return True
+    if t in ("false", "f", "0", "no", "n"):
+        return False
+    raise ValueError("{0!r} is not a boolean".format(text))
+
+
+def _seed_type(text):
+    from .enums import MCMCSeedType
+    try:
+        return MCMCSeedType[str(text).upper()]
+    except KeyError:
+        import argparse
+        raise argparse.ArgumentTypeError("--mcmc-seed-type must be one of %s" % [e.name.lower() for e in MCMCSeedType])
+
+
+def mcmc_argparse(parser):
+    """The sampler's command-line group, as the reference's scripts compose it (golemflavor/mcmc.py:56-85: same flags,
+    types and defaults): --run-mcmc, --burnin 100, --nwalkers 60, --nsteps 2000, --mcmc-seed-type uniform|gaussian,
+    --plot-angles, --plot-elements (the plotting flags are accepted and carried; plotting is out of scope here)."""
+    from .enums import MCMCSeedType
+    g = parser
+    g.add_argument('--run-mcmc', type=_flag, default=True, help='Run the MCMC')
+    g.add_argument('--burnin', type=int, default=100, help='Amount to burnin')
+    g.add_argument('--nwalkers', type=int, default=60, help='Number of walkers')
+    g.add_argument('--nsteps', type=int, default=2000, help='Number of steps to run')
+    g.add_argument('--mcmc-seed-type', type=_seed_type, default=MCMCSeedType.UNIFORM, choices=list(MCMCSeedType),
+                   help='Type of distrbution to make the initial MCMC seed')
+    g.add_argument('--plot-angles', type=_flag, default=False, help='Plot MCMC triangle in the angles space')
+    g.add_argument('--plot-elements', type=_flag, default=False, help='Plot MCMC triangle in the mixing elements space')
+    return parser
+
+
 def solve_ratio(fr):
     """'1_2_0' for small-integer ratios, else two-decimal floats (golemflavor/misc.py:34-41; the reference
     reduces with a floating-point gcd, restated here with a tolerance)."""

@@ -19,6 +19,7 @@ import time
 
 import numpy as np
 
+from . import _lib
 from . import configs as Cf
 from . import dist as gdist
 from . import fr as fr_utils
@@ -122,6 +123,7 @@ class _SensPoint:
 
 
 PHASES = {}          # wall-clock seconds of the last run_points call, by phase (reported by main)
+GATHER_STATS = {}     # the last DeviceGather.run: bytes and seconds by phase
 LAST_NONUNITARY = {}  # the last stacked run_points call: proposals the reference would have raised on, and how they were settled
 
 
@@ -229,7 +231,9 @@ class DeviceGather:
         first = jobs[order[0]]
         per = sampler.nstored * first.nwalkers                    # samples per grid point
         width = first.ndim if first.post_model is None else 3 + first.ndim
-        self.stats = {"ranks": self.world, "slots_per_rank": slots}
+        self.stats = GATHER_STATS
+        self.stats.clear()
+        self.stats.update({"ranks": self.world, "slots_per_rank": slots})
         if self.rccl is None and self.world == 1 and first.post_model is not None:
             # one rank: no exchange -- rows to the host group by group while the later chains are still post-processed
             t0 = time.perf_counter()
@@ -330,6 +334,8 @@ def main(argv=None):
                           "gather": ("rccl device gather to rank 0" if rccl is not None else "device -> host") if device_gather
                           else ("socket control plane" if world > 1 else "local"),
                           "rccl_error": rccl_err, "librccl": gdist.rccl_library_info(),
+                          "diagnostic_overrides": _lib.diagnostic_overrides(),
+                          "gather_stats": GATHER_STATS, "nonunitary": LAST_NONUNITARY,
                           "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,
                           "phases": {k: round(v, 4) for k, v in PHASES.items()},
                           "evals_per_s": len(pts) * evals_per_point / dt,

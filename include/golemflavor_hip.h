@@ -43,7 +43,10 @@ typedef enum gf_error {
     GF_ERR_HIP = 3,           /* a HIP runtime call failed; gf_last_hip_error() has the string  */
     GF_ERR_ALLOC = 4,
     GF_ERR_COMM = 5,          /* RCCL failure                                                   */
-    GF_ERR_UNSUPPORTED = 6
+    GF_ERR_UNSUPPORTED = 6,
+    GF_ERR_QUEUE_OVERFLOW = 7 /* ABI 3: a unitarity work queue was found full on the device and (walker, bin) pairs were dropped:
+                                 the status array of that batch is incomplete.  The host sizes batches to fit, so this is a
+                                 library bug surfacing loudly instead of as a silently missing verdict                     */
 } gf_error;
 
 /* per-walker outcome.  Reference behaviour: OUT_OF_PRIOR -> ln_prob returns -inf (llh.py:74-78,
@@ -122,7 +125,14 @@ int gf_abi_version(void);
 const char* gf_strerror(int err);
 const char* gf_last_hip_error(void);   /* thread-local text of the last failing HIP/RCCL call    */
 size_t gf_sizeof_model_desc(void);     /* sizeof(gf_model_desc) as compiled: lets a binding verify its layout */
+/* ABI 3.  "NAME=value ..." of every GF_* environment override this process's library has honoured so far ("" = none).  The ones
+ * that can change a result (the unitarity tiers' thresholds, GF_UNI_DUMP) are honoured only under GF_DIAGNOSTICS=1 and listed
+ * as "NAME(ignored)" otherwise; bench.py and scan.py print the list in their JSON line. */
+int gf_diagnostic_overrides(char* buf, size_t buflen);
 int gf_device_count(int* count);
+/* ABI 3.  Hand back the device memory the library caches between uses on `device`: the unitarity workspaces of idle pooled
+ * streams (up to 8 GiB) and pooled constant blocks.  *released_bytes may be NULL. */
+int gf_device_trim(int device, size_t* released_bytes);
 int gf_device_name(int device, char* buf, size_t buflen);   /* gcnArchName, e.g. "gfx950:..."   */
 
 /* ---- model ------------------------------------------------------------------------------ */

@@ -84,6 +84,16 @@ def test_rccl_binding_world_size_1():
         assert got.shape == (1, 250, 4) and np.array_equal(got[0], x)
         chains = gdist.gather_chains({0: x, 1: x + 1}, 2, b, allgather=lambda a: b.allgather(a, m))
         assert np.array_equal(chains[1], x + 1)
+        # gather to root (ABI 3): on one rank the block lands in the root's buffer, equal to the local block
+        d_send, d_recv = m.alloc(x.nbytes).upload(x), m.alloc(x.nbytes)
+        b.gather_device(d_send.ptr, d_recv.ptr, x.nbytes, 0)
+        assert np.array_equal(d_recv.download(x.shape), x)
+        b.gather_device(d_send.ptr, d_send.ptr, x.nbytes, 0)           # in place: nothing to copy
+        assert np.array_equal(d_send.download(x.shape), x)
+        import ctypes as C
+        L = _lib.lib()
+        assert L.gf_comm_gather(b._h, d_send.ptr, None, x.nbytes, 0) == _lib.GF_ERR_INVALID_ARG    # the root needs a destination
+        assert L.gf_comm_gather(b._h, d_send.ptr, d_recv.ptr, x.nbytes, 1) == _lib.GF_ERR_INVALID_ARG  # root outside the world
     b.barrier()
     b.close()
 
@@ -130,7 +140,7 @@ def test_grid_scan_writes_reference_named_files(capsys, tmp_path):
 
 def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
     """The chain gather of a scan through the library's RCCL communicator (one rank here; the same code path
-    all-gathers over xGMI on N ranks): result identical to the local gather."""
+    gathers to rank 0 over xGMI on N ranks): result identical to the local gather."""
     import json
     from golemflavor_amd import scan
     args = ["--config", "C4", "--points", "3", "--nwalkers", "32", "--burnin", "10", "--nsteps", "15"]
@@ -139,9 +149,26 @@ def test_grid_scan_gathers_over_rccl(capsys, monkeypatch, tmp_path):
     monkeypatch.setenv("GF_SCAN_RCCL", "1")
     scan.main(args + ["--outfile", str(tmp_path / "rccl")])
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert out["gather"] == "rccl device all-gather" and out["rccl_error"] is None
+    assert out["gather"] == "rccl device gather to rank 0" and out["rccl_error"] is None
     a, b = np.load(str(tmp_path / "local.npy")), np.load(str(tmp_path / "rccl.npy"))
     assert a.shape == (3, 32 * 15, 9) and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("config", ["C4", "C5"])
+def test_reference_length_scan_on_one_gpu(config):
+    """BASELINE configs C4 / C5 at FULL size and at the reference's own chain length (burnin 200 + 1000 stored steps,
+    submitter/mc_texture_dag.py:33-39), one rank: the chain buffer grows through its doublings (64 -> 1024 slots, repacked on
+    the device), C4's 131 M stored samples go through the flux-averaged post-processing with the unitarity verdict, and
+    7-13 GB of rows cross PCIe in chunks -- bench.py's c4_scan_ref / c5_scan_ref code path."""
+    import bench
+    rec = bench.extra_scan(0, config, bench.REF_BURNIN, bench.REF_NSTEPS)
+    assert "error" not in rec
+    npts, nw, width = (64, 2048, 9) if config == "C4" else (256, 512, 12)
+    assert rec["ranks"] == 1 and rec["grid_points"] == npts and rec["burnin"] == 200 and rec["nsteps"] == 1000
+    assert rec["chain_bytes_to_host"] == npts * nw * 1000 * width * 8
+    assert rec["finite_fraction"] > (0.6 if config == "C4" else 0.999)      # C4's top scales sit in the failing region (NaN rows)
+    assert rec["sampling_s"] > 0 and rec["d2h_s"] > 0 and rec["seconds"] < 60.0
+    assert rec["evals_per_s"] > 1e8
 
 
 def test_scan_rows_to_host_equal_rows_on_device():

@@ -1,0 +1,146 @@
+"""GPU, round 3: args.no_bsm, the unitarity queues' overflow report, gf_device_trim."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import BIN_EDGES, uniform_theta
+from golemflavor_amd import _lib
+from golemflavor_amd import configs as Cf
+from golemflavor_amd import fr as fr_utils
+from golemflavor_amd import llh as llh_utils
+from golemflavor_amd.descriptor import compile_model
+from golemflavor_amd.enums import Texture
+from golemflavor_amd.model import Model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_bsm_is_the_standard_propagation_on_the_device(oracle):
+    """args.no_bsm (golemflavor/fr.py:437-438).  PARITY UNPINNED: the reference's own branch cannot run (it hands u_to_fr a
+    2-D source flux), so there is no reference output; the build defines it as u_to_fr(source_ratio, sm_u)
+    and this test holds the device to the oracle's u_to_fr / lnprior / multi_gaussian restatements (each pinned on its own
+    golden set) composed that way -- and checks that the BSM machinery is really out of the loop."""
+    rng = np.random.default_rng(5)
+    asimov, ps = Cf.fr_paramsets(6, fr_utils.fr_to_angles((1, 1, 1)))
+    src = np.array([0.0, 1.0, 0.0])
+    args = argparse.Namespace(source_ratio=src, dimension=6, texture=Texture.OEU, binning=BIN_EDGES, no_bsm=True)
+    th = uniform_theta(ps, 5000, rng, seeds=True)
+    th[:, 11] = rng.uniform(-56, -30, len(th))                  # logLam over the whole range, failing region included
+    th[::97, 0] = 1.5                                           # some rows outside the box
+    om = oracle.make_model(ps, "SM_GAUSS", bestfit_fr=(1 / 3,) * 3, smearing=0.02, source_ratio=src)
+    assert list(om.idx_sm) == [0, 1, 2, 3] and list(om.idx_src) == [-1, -1]
+    want_lp, want_fr = oracle.lnprob_batch(om, th, want_fr=True)
+    # the reference-named entry points
+    frs = fr_utils.flux_averaged_BSMu(th, args, -2.0, ps)
+    ok = np.isfinite(want_lp)
+    assert np.abs(frs[ok] - want_fr[ok]).max() < 1e-10
+    one = fr_utils.flux_averaged_BSMu(th[1], args, -2.0, ps)
+    assert one.shape == (3,) and np.abs(one - want_fr[1]).max() < 1e-10
+    f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.02)   # on_nonunitary="raise": nothing may raise, nothing is diagonalised
+    lp = f(th)
+    assert np.array_equal(np.isneginf(lp), np.isneginf(want_lp)) and np.isneginf(lp[::97]).all()
+    assert np.max(np.abs(lp[ok] - want_lp[ok]) / np.abs(want_lp[ok])) < 1e-10
+    assert f.model.mode == _lib.GF_MODE_SM_GAUSS
+    # independent of the new-physics scale: the same rows with another logLam give the same composition
+    th2 = th.copy()
+    th2[:, 11] = -50.0
+    assert np.array_equal(fr_utils.flux_averaged_BSMu(th2, args, -2.0, ps)[ok], frs[ok])
+    # and it is NOT what the BSM path returns at a high scale
+    args.no_bsm = False
+    args.texture = Texture.OET
+    th3 = th[ok][:64].copy()
+    th3[:, 11] = -42.0
+    assert np.abs(fr_utils.flux_averaged_BSMu(th3, args, -2.0, ps) - want_fr[ok][:64]).max() > 1e-3
+    f.close()
+    # a paramset without the mass splittings: NuFIT mixing whatever theta holds (fr.py:433-435)
+    ps4 = Cf.unitary_paramset()
+    args4 = argparse.Namespace(source_ratio=np.array([1.0, 2.0, 0.0]) / 3, dimension=3, texture=Texture.OUT, binning=BIN_EDGES,
+                               no_bsm=True)
+    got = fr_utils.flux_averaged_BSMu(uniform_theta(ps4, 16, rng), args4, -2.0, ps4)
+    nufit = np.asarray(fr_utils.u_to_fr((1, 2, 0), fr_utils.NUFIT_U), dtype=float)
+    assert np.abs(got - nufit).max() < 1e-12
+
+
+_OVERFLOW_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from common import BIN_EDGES, uniform_theta
+from golemflavor_amd import _lib, configs as Cf
+from golemflavor_amd.descriptor import compile_model
+from golemflavor_amd.enums import Texture
+from golemflavor_amd.model import Model
+ps = Cf.texture_paramset(6)
+rng = np.random.default_rng(2)
+n = 400_000
+th = uniform_theta(ps, n, rng, seeds=True)
+th[:, -1] = rng.uniform(-56, -30, n)
+desc = compile_model(ps, "BSM_GAUSS", texture=Texture.OEU, dimension=6, binning=BIN_EDGES, source_ratio=(0., 1., 0.),
+                     bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+out = []
+with Model(desc) as m:
+    try:
+        m.lnprob(th)
+        out.append("host:ok")
+    except _lib.GolemHipError as exc:
+        out.append("host:%d" % exc.code)
+    d_th = m.alloc(th.nbytes).upload(th); d_out, d_st = m.alloc(8 * n), m.alloc(4 * n)
+    m.lnprob_device(d_th.ptr, n, d_out.ptr, None, d_st.ptr)
+    try:
+        m.sync()
+        out.append("device:ok")
+    except _lib.GolemHipError as exc:
+        out.append("device:%d" % exc.code)
+    # the report is consumed: a batch that fits goes through afterwards
+    lp, st = m.lnprob(th[:1000])
+    out.append("after:%d" % int(np.sum(st == 2) > 0))
+print(" ".join(out), "|" + _lib.diagnostic_overrides())
+"""
+
+
+def test_a_full_unitarity_queue_is_reported_not_swallowed(tmp_path):
+    """queue_pairs drops a (walker, bin) pair when the arbitration queue is full.  The host cuts batches so that this
+    cannot happen; if the invariant is ever broken the call must FAIL (GF_ERR_QUEUE_OVERFLOW), not return statuses with
+    verdicts missing.  The invariant is broken on purpose here: GF_DIAG_UQ_OVERCOMMIT (pieces 4x what the queue holds, a
+    result-changing override: needs GF_DIAGNOSTICS=1) with EVERY (walker, bin) pair sent to arbitration (tier 1 off, band of 12
+    decades) through a 131 072-item queue."""
+    script = tmp_path / "child.py"
+    script.write_text(_OVERFLOW_CHILD)
+    env = dict(os.environ, GF_DIAGNOSTICS="1", GF_DIAG_UQ_OVERCOMMIT="1", GF_UQ_MAX_ITEMS="131072", GF_UNI_BAND_DECADES="12",
+               GF_UNI_NO_WEIGHT_GATE="1", PYTHONDONTWRITEBYTECODE="1")
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = res.stdout.strip().splitlines()[-1]
+    assert line.startswith("host:%d device:%d after:1 |" % (_lib.GF_ERR_QUEUE_OVERFLOW, _lib.GF_ERR_QUEUE_OVERFLOW)), line
+    assert "GF_DIAG_UQ_OVERCOMMIT=1" in line and "GF_UNI_BAND_DECADES=12" in line
+    # without the deliberate overcommit the same run is clean
+    env.pop("GF_DIAG_UQ_OVERCOMMIT")
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert res.stdout.strip().splitlines()[-1].startswith("host:ok device:ok after:1 |")
+
+
+def test_device_trim_releases_idle_workspaces():
+    """gf_device_trim hands back what the pool keeps between uses: after a status batch the stream's unitarity workspace
+    (queues + side buffer, ~170 B per walker) stays with the pooled stream; trim frees it, and the next model works."""
+    ps = Cf.texture_paramset(6)
+    rng = np.random.default_rng(3)
+    n = 200_000
+    th = uniform_theta(ps, n, rng, seeds=True)
+    th[:, -1] = rng.uniform(-56, -36, n)
+    desc = compile_model(ps, "BSM_GAUSS", texture=Texture.OET, dimension=6, binning=BIN_EDGES, source_ratio=(0., 1., 0.),
+                         bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    with Model(desc) as m:
+        want = m.lnprob(th)
+    freed = _lib.device_trim(0)
+    assert freed >= n * 20 * 8                                   # at least the arbitration queue of that batch
+    assert _lib.device_trim(0) < freed                           # nothing of that size left to free
+    with Model(desc) as m:
+        got = m.lnprob(th)
+    assert np.array_equal(want[0], got[0], equal_nan=True) and np.array_equal(want[1], got[1])
+    assert _lib.lib().gf_device_trim(99, None) == _lib.GF_ERR_NO_DEVICE

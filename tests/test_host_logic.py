@@ -308,3 +308,61 @@ def test_host_sampler_thinning_counts_every_iteration():
     unthinned.run_mcmc(p0, 30)
     assert np.array_equal(unthinned.chain[:, ::3], s.chain[:, :10])       # same random stream, every third step kept
     assert np.array_equal(unthinned.naccepted / 30, unthinned.acceptance_fraction)
+
+
+# ---------------------------------------------------------------- round 3: no_bsm, mcmc_argparse, override record
+def test_no_bsm_compiles_to_the_standard_propagation():
+    """args.no_bsm (fr.py:437-438; the reference's branch cannot run): defined as u_to_fr(source_ratio, sm_u)
+    with the flux average's own column rule -- mixing angles from theta only when all six oscillation parameters are scanned."""
+    ps12 = Cf.fr_paramsets(6, (0.5, 0.0))[1]
+    kw = dict(bestfit_fr=(1 / 3,) * 3, smearing=0.02, source_ratio=(0.0, 1.0, 0.0), texture=Texture.OET, dimension=6,
+              binning=BIN_EDGES)
+    d = compile_model(ps12, "BSM_GAUSS", no_bsm=True, **kw)
+    assert d.mode == _lib.GF_MODE_SM_GAUSS and d.ndim == 12 and d.nbins == 0
+    assert list(d.idx_sm) == [0, 1, 2, 3] and list(d.idx_src) == [-1, -1] and d.idx_src_x == -1
+    assert list(d.source_ratio) == [0.0, 1.0, 0.0]
+    # without the mass splittings among the columns the angles are NOT taken from theta (fr.py:433-435: NuFIT)
+    ps4 = Cf.mcx_paramset()
+    d4 = compile_model(ps4, "BSM_GAUSS", no_bsm=True, **kw)
+    assert list(d4.idx_sm) == [-1] * 4 and d4.idx_src_x == -1 and list(d4.sm_fixed) == list(Cf.NUFIT_ANGLES)
+    with pytest.raises(ValueError):
+        compile_model(ps12, "SM_GAUSS", no_bsm=True, bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+    # the BSM descriptor itself is unchanged by the new keyword's default
+    assert bytes(memoryview(compile_model(ps12, "BSM_GAUSS", **kw))) == bytes(memoryview(compile_model(ps12, "BSM_GAUSS", no_bsm=False, **kw)))
+
+
+def test_mcmc_argparse_has_the_reference_flags_and_defaults():
+    """golemflavor/mcmc.py:56-85."""
+    import argparse
+    from golemflavor_amd import mcmc as mcmc_utils
+    from golemflavor_amd.enums import MCMCSeedType
+    p = mcmc_utils.mcmc_argparse(argparse.ArgumentParser())
+    a = p.parse_args([])
+    assert (a.run_mcmc, a.burnin, a.nwalkers, a.nsteps, a.mcmc_seed_type, a.plot_angles, a.plot_elements) == \
+        (True, 100, 60, 2000, MCMCSeedType.UNIFORM, False, False)
+    a = p.parse_args("--run-mcmc False --burnin 200 --nwalkers 2048 --nsteps 1000 --mcmc-seed-type gaussian --plot-angles True".split())
+    assert (a.run_mcmc, a.burnin, a.nwalkers, a.nsteps, a.mcmc_seed_type, a.plot_angles) == \
+        (False, 200, 2048, 1000, MCMCSeedType.GAUSSIAN, True)
+    with pytest.raises(SystemExit):
+        p.parse_args(["--mcmc-seed-type", "cauchy"])
+
+
+def test_result_changing_overrides_need_gf_diagnostics(tmp_path):
+    """A stray GF_UNI_* variable must not change verdicts silently: without GF_DIAGNOSTICS=1 it is ignored (and listed as
+    ignored); with it, it is honoured and listed.  Child processes: the record is per process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from golemflavor_amd import _lib\n"
+            "import ctypes as C\n"
+            "L = _lib.lib()\n"
+            "L.gf_internal_env.restype = C.c_char_p; L.gf_internal_env.argtypes = [C.c_char_p, C.c_int]\n"
+            "v = L.gf_internal_env(b'GF_UNI_A_OK', 1); w = L.gf_internal_env(b'GF_SAMPLER_LPW', 0)\n"
+            "print(repr(v), repr(w), '|' + _lib.diagnostic_overrides())\n" % ROOT)
+    env = dict(os.environ, GF_UNI_A_OK="1e-9", GF_SAMPLER_LPW="4")
+    env.pop("GF_DIAGNOSTICS", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "None b'4' |GF_UNI_A_OK(ignored) GF_SAMPLER_LPW=4" and "ignored" in out.stderr
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GF_DIAGNOSTICS="1"), timeout=60)
+    assert out.stdout.strip() == "b'1e-9' b'4' |GF_UNI_A_OK=1e-9 GF_SAMPLER_LPW=4"

@@ -16,6 +16,7 @@ for dim, tex, twelve in ((6, Texture.OEU, True), (3, Texture.OUT, False), (6, Te
     kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(0., 1., 0.), bestfit_fr=(1/3,)*3, smearing=0.02)
     for dec_env in ("0", "2", "3", "4"):
         os.environ["GF_UNI_BAND_DECADES"] = dec_env
+        os.environ["GF_DIAGNOSTICS"] = "1"      # result-changing overrides are honoured only with this set
         with Model(compile_model(ps, "BSM_GAUSS", texture=tex, **kw)) as m:
             d_th = m.alloc(th.nbytes).upload(th); d_out = m.alloc(8*n); d_st = m.alloc(4*n)
             for rep in range(2):

@@ -12,7 +12,7 @@ from golemflavor_amd.enums import Texture
 from golemflavor_amd.model import Model
 from oracle import oracle
 from common import BIN_EDGES, uniform_theta
-os.environ["GF_UNI_DUMP"] = "1"; os.environ["GF_UNI_NO_WEIGHT_GATE"] = "1"
+os.environ["GF_DIAGNOSTICS"] = "1"; os.environ["GF_UNI_DUMP"] = "1"; os.environ["GF_UNI_NO_WEIGHT_GATE"] = "1"
 cent = np.sqrt(BIN_EDGES[:-1] * BIN_EDGES[1:])
 rows = []
 for dim in (4, 5, 6, 7, 8):
