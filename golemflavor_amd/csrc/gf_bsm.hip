@@ -53,16 +53,18 @@ using namespace gfdev;
 #endif
 // (the generic-width instances, NDIM = 0, index the row at run time and need ~180: two waves)
 #define GF_BSM_WAVES(UM, ND) ((ND) == 0 ? 2 : (UM) == UNI_NONE ? GF_BSM_WAVES_NONE : (UM) == UNI_DEFER ? GF_BSM_WAVES_DEFER : GF_BSM_WAVES_INLINE)
-// Push the undecided bins of walker `i` (bit k of `amb` = energy bin k) onto the arbitration queue
-__device__ __forceinline__ void queue_pairs(GfUniQueue* __restrict__ uq, int64_t i, unsigned long long amb)
+// Queue walker `i` for the arbitration with its undecided bins (bit k of `amb` = energy bin k)
+__device__ __forceinline__ void queue_walker(GfArbQueue* __restrict__ uq, int64_t i, unsigned long long amb)
 {
-    const unsigned int cnt = (unsigned int)__popcll(amb);
-    const unsigned int at = atomicAdd(&uq->count, cnt);
-    unsigned int j = 0;
-    for (unsigned long long mrest = amb; mrest != 0; mrest &= mrest - 1, ++j)
-        if (at + j < uq->cap) uq->items[at + j] = (unsigned long long)i * 64ull + (unsigned long long)(__ffsll((long long)mrest) - 1);
-        else uq->overflow = 1u;            // cannot happen while the host cuts batches to fit (gf_launch_bsm); if it ever does,
-                                           // the dropped pair's verdict is missing and the host call fails (GF_ERR_QUEUE_OVERFLOW)
+    const unsigned int at = atomicAdd(&uq->count, 1u);
+    if (at < uq->cap) {
+        GfArbItem it;
+        it.walker = (unsigned long long)i;
+        it.mask = amb;
+        uq->items[at] = it;
+    } else {
+        uq->overflow = 1u;                 // cannot happen while the host cuts batches to fit (gf_launch_bsm); if it ever does,
+    }                                      // the dropped walker's verdict is missing and the host call fails (GF_ERR_QUEUE_OVERFLOW)
 }
 
 // LPW > 1 (small batches: a host-driven emcee half-ensemble is a few hundred walkers, i.e. a few waves on 1024
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
                                                       const double* __restrict__ ptab,
                                                       const double* __restrict__ theta, int layout, int64_t n,
                                                       double* __restrict__ lnprob, double* __restrict__ fr_out,
-                                                      int32_t* __restrict__ status, GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq,
+                                                      int32_t* __restrict__ status, GfArbQueue* __restrict__ uq, GfUniQueue* __restrict__ wq,
                                                       double* __restrict__ t2sn)
 {
     constexpr bool CHECK_UNI = UNI_MODE == UNI_INLINE;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
                     if (!(acc.clear_max < tb->uni_hi)) st = ST_NON_UNITARY;
                     // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
                     // walker counts as unitary
-                    else if (inbox && acc.amb != 0 && sub == 0 && uq) queue_pairs(uq, i, acc.amb);
+                    else if (inbox && acc.amb != 0 && sub == 0 && uq) queue_walker(uq, i, acc.amb);
                 }
                 if (UNI_MODE == UNI_DEFER) defer = inbox && acc.a_min < tb->uni_a_ok;      // tier 1 does not clear this walker
                 if (WITH_LLH) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
 #endif
 __global__ __launch_bounds__(GF_BLOCK, GF_T2_WAVES) void k_bsm_tier2(const GfBsm* __restrict__ tb, const double* __restrict__ t2sn, int64_t n,
                                                                      double* __restrict__ lnprob, int32_t* __restrict__ status,
-                                                                     GfUniQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
+                                                                     GfArbQueue* __restrict__ uq, GfUniQueue* __restrict__ wq)
 {
     const unsigned int count = wq->count < wq->cap ? wq->count : wq->cap;
     for (unsigned int q = blockIdx.x * GF_BLOCK + threadIdx.x; q < count; q += gridDim.x * GF_BLOCK) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_T2_WAVES) void k_bsm_tier2(const GfBsm
             status[i] = ST_NON_UNITARY;
             if (lnprob) lnprob[i] = gf_nan();
         } else if (acc.amb != 0) {
-            queue_pairs(uq, i, acc.amb);
+            queue_walker(uq, i, acc.amb);
         }
     }
     // the walker queue is re-armed by k_uni_resolve, which follows in stream order (one store there instead of a fence
@@ -327,7 +329,7 @@ inline int lanes_for(int64_t n, int nbins, int cus, bool check)
 
 template <int NDIM, int LPW>
 hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
+                     int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfArbQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
 {
     const int grid = grid_for(n * LPW, GF_BLOCK, cus);
     const size_t lds = LPW > 1 ? (size_t)(GF_BLOCK / LPW) * GF_FGRP_DOUBLES(nbins, LPW) * sizeof(double) : 0;
@@ -348,7 +350,7 @@ hipError_t launch_nl(const GfCommon& c, const GfCommon* d_common, const GfBsm* d
 
 template <int NDIM>
 hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout, int64_t n,
-                    int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
+                    int with_llh, double* lnprob, double* fr, int32_t* status, GfArbQueue* uq, GfUniQueue* wq, double* t2sn, int cus, hipStream_t s)
 {
     switch (lanes_for(n, nbins, cus, status != nullptr)) {
     case 4: return launch_nl<NDIM, 4>(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, uq, nullptr, nullptr, cus, s);
@@ -363,7 +365,7 @@ hipError_t launch_n(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_
 // whole batch and `n` = its size).  `uq` (status requested): where undecided (walker, bin) pairs go; `qbase` is added to
 // the walker index in the queue.
 static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta,
-                              int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, GfUniQueue* wq,
+                              int layout, int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfArbQueue* uq, GfUniQueue* wq,
                               double* t2sn, int cus, hipStream_t s)
 {
     switch (c.ndim) {
@@ -373,16 +375,16 @@ static hipError_t launch_eval(const GfCommon& c, const GfCommon* d_common, const
     }
 }
 
-// `uq` / `uq_cap` (items): the model's arbitration queue, NULL / 0 when no status array is requested; `wq`: its queue of
+// `uq` / `uq_cap` (items = walkers): the stream's arbitration queue, NULL / 0 when no status array is requested; `wq`: its queue of
 // walkers for k_bsm_tier2 (`wq_cap` walkers) and `t2sn` their Hamiltonian terms ([wq_cap][18]), NULL = tiers inline.  With a status array
-// an AoS batch is cut into pieces whose worst case (every bin of every walker undecided) fits the queue, each piece
+// an AoS batch is cut into pieces whose worst case (every walker undecided) fits the queues, each piece
 // followed by the resolve kernel: evaluation and arbitration stay in stream order, nothing is read back.
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfArbQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
                          double* t2sn, unsigned int* seen, int cus, hipStream_t s)
 {
     if (!status || !uq) return launch_eval(c, d_common, d_bsm, nbins, ptab, theta, layout, n, with_llh, lnprob, fr, status, nullptr, nullptr, nullptr, cus, s);
-    int64_t piece = uq_cap / (nbins > 0 ? nbins : 1);
+    int64_t piece = uq_cap;
     if (wq && wq_cap < piece) piece = wq_cap;                            // ... and the walker queue of the deferred tier 2
     // diagnostics only (needs GF_DIAGNOSTICS=1): pieces four times what the queues hold, to exercise the overflow report
     static const bool overcommit = gf_internal_env("GF_DIAG_UQ_OVERCOMMIT", 1) != nullptr;
@@ -396,7 +398,7 @@ hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBs
                                    lnprob ? lnprob + w0 : nullptr, fr ? fr + 3 * w0 : nullptr, status + w0, uq, wq, t2sn, cus, s);
         if (e != hipSuccess) return e;
         e = gf_launch_uni_resolve(d_common, d_bsm, layout == 0 ? theta + w0 * c.ndim : theta, layout, m, c.ndim,
-                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, wq, m * nbins, seen, cus, s);
+                                  with_llh && lnprob ? lnprob + w0 : nullptr, status + w0, uq, wq, m, seen, cus, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

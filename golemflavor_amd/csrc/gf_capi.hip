@@ -164,14 +164,14 @@ constexpr size_t CONST_BLOCK_BYTES = CONST_COMMON_OFFSET + sizeof(GfCommon);
 // the stream goes back to the pool.
 struct UniWork {
     std::mutex mu;                 // held from sizing the workspace to the last launch that uses it
-    GfUniQueue* d_uq = nullptr;    // [uq_cap] (walker, bin) pairs
+    GfArbQueue* d_uq = nullptr;    // [uq_cap] walkers with their undecided bins
     GfUniQueue* d_wq = nullptr;    // [wq_cap] walkers
     double* d_t2sn = nullptr;      // [wq_cap][18]
     unsigned int* h_seen = nullptr;
     int64_t uq_cap = 0, wq_cap = 0;
     size_t bytes() const
     {
-        return (d_uq ? sizeof(unsigned long long) * (size_t)uq_cap : 0) + (d_wq ? sizeof(unsigned long long) * (size_t)wq_cap : 0) +
+        return (d_uq ? sizeof(GfArbItem) * (size_t)uq_cap : 0) + (d_wq ? sizeof(unsigned long long) * (size_t)wq_cap : 0) +
                (d_t2sn ? sizeof(double) * 18 * (size_t)wq_cap : 0);
     }
     void release()
@@ -179,7 +179,7 @@ struct UniWork {
         if (d_uq) (void)hipFree(d_uq);
         if (d_wq) (void)hipFree(d_wq);
         if (d_t2sn) (void)hipFree(d_t2sn);
-        d_uq = d_wq = nullptr; d_t2sn = nullptr; uq_cap = wq_cap = 0;
+        d_uq = nullptr; d_wq = nullptr; d_t2sn = nullptr; uq_cap = wq_cap = 0;
     }
 };
 
@@ -320,10 +320,10 @@ int check_dev_ptr(const void* p, size_t align)
     return GF_OK;
 }
 
-// The arbitration queue must hold every (walker, bin) pair of one piece of the batch (gf_launch_bsm cuts AoS batches
-// into pieces of uq_cap / nbins walkers; SoA batches go in one piece).
-constexpr int64_t UQ_MAX_ITEMS = 1 << 27;      // 1 GiB of items at most: ~6.7 M walkers x 20 bins per piece (allocated only
-                                               // when a status array is asked for on a batch that large; 288 GB of HBM)
+// The arbitration queue must hold every walker of one piece of the batch (gf_launch_bsm cuts AoS batches into pieces of
+// uq_cap walkers; SoA batches go in one piece).  Items are walkers since round 3 (16 B each: index + mask of undecided bins),
+// not (walker, bin) pairs: a queue for the 8.4 M walkers of a piece is 128 MiB where round 2's was 1 GiB for 6.7 M.
+constexpr int64_t UQ_MAX_ITEMS = 1 << 23;
 // from this batch size on (one lane per walker in the evaluation kernel) tier 2 runs as its own compact kernel
 constexpr int64_t GF_TIER2_SPLIT_MIN = 65536;
 constexpr int64_t WQ_MAX_WALKERS = 1 << 23;    // per piece: 8.4 M walkers, 1.2 GB of side buffer
@@ -331,12 +331,13 @@ constexpr int64_t WQ_MAX_WALKERS = 1 << 23;    // per piece: 8.4 M walkers, 1.2 
 // `items_limit` (out): how many items of the queue a piece of this batch may use (its capacity, or GF_UQ_MAX_ITEMS if smaller)
 int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int64_t* items_limit)
 {
-    const int64_t nb = nbins > 0 ? nbins : 1;
-    int64_t need = n * nb;
+    (void)nbins;
+    const int64_t nb = 1;                     // one item per walker
+    int64_t need = n;
     int64_t max_items = UQ_MAX_ITEMS;
     if (const char* e = gf_internal_env("GF_UQ_MAX_ITEMS", 0)) {     // tests: a small queue, so that a modest batch is cut into pieces
         const long long v = std::atoll(e);
-        if (v >= 65536 && v < UQ_MAX_ITEMS) max_items = v;
+        if (v >= 4096 && v < UQ_MAX_ITEMS) max_items = v;
     }
     if (layout == GF_LAYOUT_AOS && need > max_items) need = max_items > nb ? max_items : nb;
     *items_limit = layout == GF_LAYOUT_AOS ? (max_items > nb ? max_items : nb) : (int64_t)0x7fffffffffffLL;
@@ -349,6 +350,7 @@ int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int6
         w->h_seen[0] = 0xffffffffu;              // nothing seen yet: the first launch takes the full grid
         w->h_seen[1] = 0;                        // host-only flag: full grids on request (gf_internal_full_arbitration_grids)
         w->h_seen[2] = 0;                        // written by k_uni_resolve: a queue overflowed (check_queue_overflow)
+        w->h_seen[3] = w->h_seen[4] = 0;         // running totals: pairs arbitrated, arbitration launches (gf_internal_uni_stats)
     }
     int64_t cap = w->uq_cap ? w->uq_cap : 4096;
     while (cap < need) cap *= 2;
@@ -367,9 +369,11 @@ int ensure_uq(UniWork* w, int nbins, hipStream_t st, int layout, int64_t n, int6
     if (cap != w->uq_cap) {
         if (w->d_uq) (void)hipFree(w->d_uq);
         w->d_uq = nullptr; w->uq_cap = 0;
-        GF_HIP(hipMalloc((void**)&w->d_uq, sizeof(GfUniQueue) + sizeof(unsigned long long) * (size_t)cap));
-        hdr.cap = (unsigned int)cap;
-        GF_HIP(hipMemcpyAsync(w->d_uq, &hdr, offsetof(GfUniQueue, items), hipMemcpyHostToDevice, st));
+        GF_HIP(hipMalloc((void**)&w->d_uq, sizeof(GfArbQueue) + sizeof(GfArbItem) * (size_t)cap));
+        GfArbQueue ah;
+        std::memset(&ah, 0, sizeof(ah));
+        ah.cap = (unsigned int)cap;
+        GF_HIP(hipMemcpyAsync(w->d_uq, &ah, offsetof(GfArbQueue, items), hipMemcpyHostToDevice, st));
         GF_HIP(hipStreamSynchronize(st));
         w->uq_cap = cap;
     }
@@ -831,7 +835,7 @@ void gf_internal_full_arbitration_grids(int device, void* stream, int on)
     if (!w->h_seen) {
         if (hipHostMalloc((void**)&w->h_seen, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w->h_seen = nullptr; return; }
         w->h_seen[0] = 0xffffffffu;
-        w->h_seen[2] = 0;
+        w->h_seen[2] = w->h_seen[3] = w->h_seen[4] = 0;
     }
     w->h_seen[1] = on ? 1u : 0u;
 }
@@ -1230,6 +1234,47 @@ int gf_model_sync(gf_model* m)
     if (!m->stream) return GF_OK;                               // no stream yet: nothing was ever enqueued
     GF_HIP(hipStreamSynchronize(m->stream));
     return check_queue_overflow(m->device, m->stream);          // of the *_device launches this call waited for
+}
+
+// internal, diagnostics (tools/): {pairs in the last arbitration launch, pairs arbitrated so far, launches so far} of the
+// model's stream (wrapping 32-bit counters); synchronise first
+int gf_internal_uni_stats(gf_model* m, unsigned int out[3])
+{
+    if (!m || !out) return GF_ERR_INVALID_ARG;
+    out[0] = out[1] = out[2] = 0;
+    if (!m->stream) return GF_OK;
+    UniWork* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool[m->device].work.find(m->stream);
+        if (it != g_pool[m->device].work.end()) w = it->second;
+    }
+    if (w && w->h_seen) { out[0] = w->h_seen[0]; out[1] = w->h_seen[3]; out[2] = w->h_seen[4]; }
+    return GF_OK;
+}
+
+// internal, diagnostics (tools/arb_probe.py): the items of the last arbitration launch on the model's stream, still in the
+// queue's memory after the kernel re-armed it: items_out[min(count, max)][2] = (walker, mask of undecided bins)
+int gf_internal_uni_dump(gf_model* m, unsigned long long* items_out, unsigned int max, unsigned int* count)
+{
+    if (!m || !items_out || !count || !m->stream) return GF_ERR_INVALID_ARG;
+    UniWork* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool[m->device].work.find(m->stream);
+        if (it != g_pool[m->device].work.end()) w = it->second;
+    }
+    if (!w || !w->h_seen || !w->d_uq) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipStreamSynchronize(m->stream));
+    unsigned int n = w->h_seen[0];
+    *count = n;
+    if (n > max) n = max;
+    if (n > (unsigned int)w->uq_cap) n = (unsigned int)w->uq_cap;
+    if (n) {
+        GF_HIP(hipMemcpyAsync(items_out, w->d_uq->items, sizeof(GfArbItem) * n, hipMemcpyDeviceToHost, m->stream));
+        GF_HIP(hipStreamSynchronize(m->stream));
+    }
+    return GF_OK;
 }
 
 // internal (gf_sampler.hip): the same report for launches the sampler put on `stream` and has just synchronised

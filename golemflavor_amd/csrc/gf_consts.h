@@ -71,8 +71,27 @@ struct GfBsm {
     double rho_max;                 // max_k epow[k] / inv2e[k]: the smallest SM weight over the bins is 1 / (1 + rho_max trN / trS)
 };
 
-// Work queue of the unitarity arbitration: (walker, energy bin) pairs whose fp64 estimate of the reference's
-// unitarity residual cannot decide the verdict.  item = walker * 64 + bin.
+// Work queue of the unitarity arbitration (gf_unitarity.hip): the WALKERS whose verdict the fp64 estimate of the reference's
+// unitarity residual cannot settle, each with the set of its undecided energy bins.  The arbitration kernel takes a walker's
+// bins from the highest energy down and stops at the first that fails (a walker is non-unitary as soon as ONE bin is,
+// fr.py:398-399 raises on the first): walkers that end up failing cost one or two bins instead of all of theirs (11 on average
+// where a posterior crosses the failing region), and the per-walker part of the chain -- mixing matrices, Hamiltonian terms -- is
+// evaluated once per walker, not once per bin.
+struct GfArbItem {
+    unsigned long long walker;      // index within the launch's piece of the batch
+    unsigned long long mask;        // bit k = energy bin k is undecided
+};
+struct GfArbQueue {
+    unsigned int count;             // items pushed by the evaluation kernels of the current launch
+    unsigned int done;              // blocks of the resolve kernel that have finished (the last one re-arms the queue)
+    unsigned int cap;               // capacity of items[]
+    unsigned int overflow;          // set by a producer that found the queue full (its item was DROPPED); k_uni_resolve reports it to the host and clears it
+    unsigned int head;              // next item to hand out (k_uni_resolve's lanes fetch their walkers dynamically)
+    unsigned int pad_[3];
+    GfArbItem items[1];             // [cap]
+};
+
+// Queue of walkers for the deferred tier 2 (k_bsm_tier2).  item = walker index.
 struct GfUniQueue {
     unsigned int count;             // items pushed by the evaluation kernel of the current launch
     unsigned int done;              // blocks of the resolve kernel that have finished (the last one resets both)

@@ -14,20 +14,20 @@ hipError_t gf_launch_propagate_sm(const GfCommon& c, const double* theta, int la
 hipError_t gf_launch_haar(const GfCommon& c, uint64_t seed, int64_t first, int64_t n, double* angles, double* fr,
                           int cus, hipStream_t s);
 // BSM (flux-averaged) path; `with_llh` = 0 -> composition only (propagate), 1 -> lnprob
-// `uq`, `uq_cap`: the model's unitarity-arbitration queue and its capacity in items (NULL / 0 when status == NULL);
+// `uq`, `uq_cap`: the stream's unitarity-arbitration queue and its capacity in items = walkers (NULL / 0 when status == NULL);
 // `wq`, `wq_cap`: its walker queue for the deferred tier 2, NULL = tiers 1-2 inline; `t2sn`: [wq_cap][18]
 // doubles, where the evaluation kernel leaves the Hamiltonian terms of the walkers it queues; `seen`: see
 // gf_launch_uni_resolve
 hipError_t gf_launch_bsm(const GfCommon& c, const GfCommon* d_common, const GfBsm* d_bsm, int nbins, const double* ptab, const double* theta, int layout,
-                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfUniQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
+                         int64_t n, int with_llh, double* lnprob, double* fr, int32_t* status, GfArbQueue* uq, int64_t uq_cap, GfUniQueue* wq, int64_t wq_cap,
                          double* t2sn, unsigned int* seen, int cus, hipStream_t s);
-// gf_unitarity.hip: settles the (walker, bin) pairs queued by the evaluation kernel in emulated x87 arithmetic; a pair the
-// reference would raise on turns status[walker] into NON_UNITARY and lnprob[walker] (if given) into NaN.  `max_items`
-// bounds the grid; the item count itself is read on the device.  `seen` (pinned host memory, may be NULL): the item count
+// gf_unitarity.hip: settles the walkers queued by the evaluation kernels in emulated x87 arithmetic, bin by bin from the highest
+// energy down; a bin the reference would raise on turns status[walker] into NON_UNITARY and lnprob[walker] (if given) into NaN
+// and ends that walker.  `max_items` (walkers) bounds the grid; the item count itself is read on the device.  `seen` (pinned host memory, may be NULL): the item count
 // of the previous launch, written by the kernel and used to size the next grid.  `wq` (may be NULL): the walker queue of
 // the deferred tier 2, emptied here for the next launch.
 hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, int ndim,
-                                 double* lnprob, int32_t* status, GfUniQueue* uq, GfUniQueue* wq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s);
+                                 double* lnprob, int32_t* status, GfArbQueue* uq, GfUniQueue* wq, int64_t max_items, unsigned int* seen, int cus, hipStream_t s);
 hipError_t gf_launch_join_rows(const double* fr, const int32_t* status, const double* theta, int ndim, int64_t n, double* out,
                                int cus, hipStream_t s);
 hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s);

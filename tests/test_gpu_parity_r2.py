@@ -357,9 +357,9 @@ def test_status_does_not_depend_on_what_the_model_ran_before():
 
 
 def test_batches_larger_than_the_arbitration_queue_are_cut_into_pieces(monkeypatch):
-    """A status batch whose (walker, bin) pairs exceed the arbitration queue (1 GiB = 6.7 M walkers of 20 bins) is cut into
-    pieces, each evaluated, tier-2'd and arbitrated in stream order.  With the queue limited to 2 M items (GF_UQ_MAX_ITEMS, read
-    per call) 300 001 walkers make three ragged pieces: results must equal those of a model that takes them in one piece."""
+    """A status batch with more walkers than the arbitration queue holds (8.4 M) is cut into pieces, each evaluated, tier-2'd
+    and arbitrated in stream order.  With the queue limited to 100 000 walkers (GF_UQ_MAX_ITEMS, read per call) 300 001
+    walkers make four ragged pieces: results must equal those of a model that takes them in one piece."""
     from common import uniform_theta
     dim, tex = 6, Texture.OEU
     ps = Cf.texture_paramset(dim)
@@ -372,7 +372,7 @@ def test_batches_larger_than_the_arbitration_queue_are_cut_into_pieces(monkeypat
     desc = compile_model(ps, "BSM_GAUSS", texture=tex, **kw)
     with Model(desc) as m:
         want = m.lnprob(th, want_fr=True)
-    monkeypatch.setenv("GF_UQ_MAX_ITEMS", "2000000")
+    monkeypatch.setenv("GF_UQ_MAX_ITEMS", "100000")
     with Model(desc) as m:
         got = m.lnprob(th, want_fr=True)
         d_th = m.alloc(th.nbytes).upload(th)
