@@ -1277,6 +1277,21 @@ int gf_internal_uni_dump(gf_model* m, unsigned long long* items_out, unsigned in
     return GF_OK;
 }
 
+// internal, test hook (tests/test_gpu_unitarity_r3.py): the emulated-x87 unitarity residual (fr.py:489-494) of explicit
+// (walker, bin) pairs of a device-resident theta block; which = 0: the serial chain of gf_x87.hpp (one lane per pair), 1: its
+// three-lane distribution (what k_uni_resolve runs).  All pointers are device pointers; synchronous.
+int gf_internal_uni_residuals(gf_model* m, const double* d_theta, int layout, int64_t n, const int64_t* d_walkers, const int32_t* d_bins,
+                              int64_t npairs, int which, double* d_out)
+{
+    if (!m || !d_theta || !d_walkers || !d_bins || !d_out || m->c.mode != GF_MODE_BSM_GAUSS) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(m->device));
+    GF_STREAM(m);
+    const hipError_t e = gf_launch_uni_debug(m->d_common, m->d_bsm, d_theta, layout, n, d_walkers, d_bins, npairs, which, d_out, m->stream);
+    if (e != hipSuccess) return hip_fail(e, "uni debug launch");
+    GF_HIP(hipStreamSynchronize(m->stream));
+    return GF_OK;
+}
+
 // internal (gf_sampler.hip): the same report for launches the sampler put on `stream` and has just synchronised
 int gf_internal_check_overflow(int device, void* stream)
 {

@@ -33,3 +33,6 @@ hipError_t gf_launch_join_rows(const double* fr, const int32_t* status, const do
 hipError_t gf_launch_flavor_hist(const double* fr, int64_t n, int nb, unsigned long long* counts, int cus, hipStream_t s);
 hipError_t gf_launch_cube_to_theta(const GfCommon& c, int nscan, const int32_t* cols, const double* base, const double* cube,
                                    int64_t n, double* theta, int cus, hipStream_t s);
+// test hook (gf_unitarity.hip): emulated-x87 residuals of explicit (walker, bin) pairs; which = 0 serial chain, 1 three-lane groups
+hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, const int64_t* walkers,
+                               const int32_t* bins, int64_t npairs, int which, double* out, hipStream_t s);

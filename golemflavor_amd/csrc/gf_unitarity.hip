@@ -29,6 +29,9 @@
 
 extern "C" const char* gf_internal_env(const char* name, int affects_results);   // gf_capi.hip: getenv with a record
 #include "gf_launch.h"
+// everything of the emulated chain inline in this translation unit: the out-of-line division / square root / sine series of
+// gf_x87.hpp's default cost k_uni_resolve a call frame (168 B of scratch per lane) and 5 % of its time (profiles/r03/ab_arbitration.txt)
+#define GFX87_INLINE_ALL
 #include "gf_x87.hpp"
 
 namespace {
@@ -37,8 +40,11 @@ using namespace gfx87;
 constexpr int TEX_NONE = 4;
 constexpr int ST_NON_UNITARY = 2;
 constexpr int UNI_BLOCK = 128;
+#ifndef GF_UNI_WAVES
+#define GF_UNI_WAVES 2                                // waves per SIMD k_uni_resolve is compiled for (~245 VGPRs)
+#endif
 #ifndef GF_UNI_BLOCKS_PER_CU
-#define GF_UNI_BLOCKS_PER_CU 8
+#define GF_UNI_BLOCKS_PER_CU (GF_UNI_WAVES * 4 * 64 / UNI_BLOCK)    // what is resident at once: later blocks would find the queue empty
 #endif
 
 __device__ inline double row_value(const double* __restrict__ theta, int layout, int64_t n, int ndim, int64_t i, int col)
@@ -89,37 +95,292 @@ __device__ __attribute__((noinline)) double walker_bin_residual(const cx87 hsm[3
     return bin_residual(hsm, hnp, pre, epow);
 }
 
-// One lane = one walker at a time.  A lane fetches a walker from the queue (one atomic per wave and round, shared out by
-// rank among the lanes that need one), builds its Hamiltonian terms, then takes its undecided bins from the highest energy
+// ---- three lanes per walker -----------------------------------------------------------------------------------------------
+// The chain of gf_x87.hpp (angles_to_u, sandwich, bin_residual / cardano_residual: the serial statement of the reference's
+// arithmetic, which the host build of that header checks against the CPU's x87 unit) distributed over the three lanes
+// r = 0, 1, 2 of a group WITHOUT changing a single operation or its order: every quantity below is computed by exactly the
+// expression the serial chain uses, only by the lane that owns it -- lane r owns row r of the 3x3 matrices, the r-th term of
+// the three-term sums (tr H^2, det), eigenvalue r and eigenvector r, two of the six entries of |X X^+| -- and what the other
+// lanes need travels through a 400-byte slot of LDS per group.  The scalar part (cubic coefficients, the arccosine) runs
+// redundantly on all three.  Matrices live in registers (a lane's rows) and LDS (H, then X): no scratch, and a walker's
+// critical path is ~2.5x shorter than on one lane.  tests/test_gpu_unitarity_r3.py compares the residuals with the serial
+// chain's, bit for bit.
+constexpr int GRP = 3;                               // lanes per walker
+constexpr int GRP_PER_WAVE = 64 / GRP;               // 21 (lane 63 idles)
+constexpr int GRP_DOUBLES = 50;                      // M[9] (36 doubles) + ex[3] (12) + 2 of padding: 400 B, LDS bank step 36
+struct Grp {
+    cx87* M;                                         // [9] H (row-major), later X; during the set-up: exchange space
+    cx87* ex;                                        // [3] exchange
+    int r;
+};
+
+__device__ __forceinline__ void grp_sync()
+{
+    // the lanes of a group sit in one wave: its LDS operations execute in order; the fences keep the compiler from moving
+    // this lane's accesses across the point where another lane's data is expected
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// row r of angles_to_u (fr.py:116-162; gf_x87.hpp angles_to_u).  Lane r evaluates "its" angle (theta12, theta13, theta23);
+// asin and acos share their one expensive step (dd_asin_small), so the three lanes run the same instructions.
+__device__ __forceinline__ void grp_angles_to_u_row(const Grp& g, const double ang[4], cx87 urow[3])
+{
+    const int r = g.r;
+    // (selects, not ang[r]: a run-time index would put the array into scratch)
+    x87 a = x_sqrt(x_from(r == 0 ? ang[0] : (r == 1 ? ang[1] : ang[2])));   // sqrt(s12^2) | c13^2 = sqrt(c13^4) | sqrt(s23^2)   fr.py:141,145-147
+    if (r == 1) a = x_sqrt(a);                                        // sqrt(c13^2)
+    // x_asin(a) / x_acos(a) for a >= 0, as dd_asin / dd_acos spell them out
+    const dd da = as_dd(a);
+    const bool small = da.hi <= 0.72;
+    const dd arg = small ? da : dd_cofunc(da);
+    const dd as = dd_asin_small(arg);
+    const bool complement = (r == 1) == small;                        // asin: beyond 0.72; acos: up to 0.72
+    const x87 t = round64(complement ? dd_sub(dd_pio2(), as) : as);
+    x87 sn, cs, sd, cd;
+    x_sincos(t, sn, cs);                                              // fr.py:149-154
+    x_sincos(x_from(ang[3]), sd, cd);                                 // exp(+-i dcp) = (cos, +-sin)
+    g.ex[r] = c_make(sn, cs);
+    grp_sync();
+    const cx87 e12 = g.ex[0], e13 = g.ex[1], e23 = g.ex[2];
+    grp_sync();
+    const x87 s12 = e12.re, c12 = e12.im, s13 = e13.re, c13 = e13.im, s23 = e23.re, c23 = e23.im;
+    const cx87 em = c_make(cd, x_neg(sd)), ep = c_make(cd, sd);
+    const cx87 s13em = c_scale(s13, em);                              // p2[0][2]
+    const cx87 ms13ep = c_scale(x_neg(s13), ep);                      // p2[2][0]
+    const x87 zero = x_from(0.0);
+    // T = p1 . p2, row r
+    const x87 fa = r == 1 ? s23 : c23, fb = r == 1 ? c23 : x_neg(s23);
+    cx87 T0 = c_scale(fa, ms13ep), T1 = c_make(fb, zero), T2 = c_make(x_mul(fa, c13), zero);
+    if (r == 0) { T0 = c_make(c13, zero); T1 = c_zero(); T2 = s13em; }
+    // u = T . p3
+    const x87 ms12 = x_neg(s12);
+    urow[0] = c_add(c_scale(c12, T0), c_scale(ms12, T1));
+    urow[1] = c_add(c_scale(s12, T0), c_scale(c12, T1));
+    urow[2] = T2;
+}
+
+__device__ __forceinline__ void grp_load_row(const double* hi, const double* lo, int r, cx87 urow[3])
+{
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = 3 * r + j;
+        const x87 re = {hi[2 * k], lo[2 * k]}, im = {hi[2 * k + 1], lo[2 * k + 1]};
+        urow[j] = c_make(re, im);
+    }
+}
+
+// row r of U diag(0, w1, w2) U^+ (gf_x87.hpp sandwich): (diag . U^+)[1][j] and [2][j] come from lane j
+__device__ __forceinline__ void grp_sandwich_row(const Grp& g, const cx87 urow[3], double w1, double w2, cx87 out[3])
+{
+    const x87 xw1 = x_from(w1), xw2 = x_from(w2);
+    g.M[g.r] = c_scale(xw1, c_conj(urow[1]));
+    g.M[3 + g.r] = c_scale(xw2, c_conj(urow[2]));
+    grp_sync();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const cx87 t1 = g.M[j], t2 = g.M[3 + j];
+        out[j] = c_add(c_mul(urow[1], t1), c_mul(urow[2], t2));
+    }
+    grp_sync();
+}
+
+// the walker's part of fr.py:380-399: row r of hsm and hnp
+__device__ __forceinline__ void grp_walker_terms(const Grp& g, const GfCommon& c, const GfBsm& tb, const double* __restrict__ theta,
+                                                            int layout, int64_t n, int64_t i, cx87 hs[3], cx87 hn[3])
+{
+    const int ndim = c.ndim;
+    cx87 urow[3];
+    if (c.idx_sm[0] >= 0) {                                             // fr.py:425-431: all six from theta, or none
+        double ang[4];
+        for (int q = 0; q < 4; ++q) ang[q] = row_value(theta, layout, n, ndim, i, c.idx_sm[q]);
+        grp_angles_to_u_row(g, ang, urow);
+    } else {
+        grp_load_row(tb.smu_hi, tb.smu_lo, g.r, urow);                  // fr.py:435 NUFIT_U (or the fixed angles)
+    }
+    const double m21 = c.idx_mass[0] >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_mass[0]) : c.mass_fixed[0];
+    const double m3x = c.idx_mass[1] >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_mass[1]) : c.mass_fixed[1];
+    grp_sandwich_row(g, urow, m21, m3x, hs);                            // fr.py:383-386 (before the 1/2E factor)
+    if (tb.texture == TEX_NONE && c.idx_mm[0] >= 0) {                   // fr.py:378, 390
+        double ang[4];
+        for (int q = 0; q < 4; ++q) ang[q] = row_value(theta, layout, n, ndim, i, c.idx_mm[q]);
+        grp_angles_to_u_row(g, ang, urow);
+    } else {
+        grp_load_row(tb.npu_hi, tb.npu_lo, g.r, urow);
+    }
+    const double ll = c.idx_scale >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_scale) : c.scale_fixed;
+    const double sc2 = cr_pow10(ll);                                    // fr.py:380 np.power(10., sc2), fp64, correctly rounded
+    const double sc1 = sc2 / 100.0;                                     // fr.py:381
+    grp_sandwich_row(g, urow, sc1, sc2, hn);                            // fr.py:391-394 (before the E^(d-3) factor)
+}
+
+// One energy bin (gf_x87.hpp bin_residual + cardano_residual, fr.py:170-237 and 489-494) on the group's three lanes; every
+// lane returns the same residual.
+__device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3], const cx87 hn[3], double pre, double epow)
+{
+    const int r = g.r;
+    cx87* M = g.M;
+    // bin_residual: the power of two that brings the larger diagonal entry to magnitude one
+    {
+        double* exd = reinterpret_cast<double*>(g.ex);
+        const double hsd = r == 0 ? hs[0].re.hi : (r == 1 ? hs[1].re.hi : hs[2].re.hi);      // the diagonal entry of this lane's row
+        const double hnd = r == 0 ? hn[0].re.hi : (r == 1 ? hn[1].re.hi : hn[2].re.hi);      // (selects: no run-time register index)
+        exd[2 * r] = fabs(pre * hsd);
+        exd[2 * r + 1] = fabs(epow * hnd);
+    }
+    grp_sync();
+    double big = 0.0;
+    {
+        const double* exd = reinterpret_cast<const double*>(g.ex);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double a = exd[2 * i], b = exd[2 * i + 1];
+            big = a > big ? a : big;
+            big = b > big ? b : big;
+        }
+    }
+    grp_sync();
+    double p2 = 1.0;
+    if (big > 0.0 && big < 1.7976931348623157e308) {
+        const int e = (int)((x_bits(big) >> 52) & 0x7ff) - 1023;
+        int k = -e;
+        k = k > 1000 ? 1000 : (k < -1000 ? -1000 : k);
+        p2 = x_from_bits((int64_t)(k + 1023) << 52);
+    }
+    const x87 xp = x_from(pre * p2), xe = x_from(epow * p2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[3 * r + j] = c_add(c_scale(xp, hs[j]), c_scale(xe, hn[j]));      // fr.py:386, 394-395
+    grp_sync();
+    // cardano_residual
+    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0), one = x_from(1.0);
+    const cx87 tr = c_add(c_add(M[0], M[4]), M[8]);
+    // tr H^2: lane r forms (H^2)_rr
+    {
+        cx87 sacc = c_mul(M[3 * r + 0], M[0 + r]);
+        sacc = c_add(sacc, c_mul(M[3 * r + 1], M[3 + r]));
+        sacc = c_add(sacc, c_mul(M[3 * r + 2], M[6 + r]));
+        g.ex[r] = sacc;
+    }
+    grp_sync();
+    const cx87 tr2 = c_add(c_add(g.ex[0], g.ex[1]), g.ex[2]);
+    grp_sync();
+    // det (fr.py:77-79): lane r forms h[r][0] * (h[p][1] h[q][2] - h[q][1] h[p][2]), (p, q) the two other rows in order
+    {
+        const int p = r == 0 ? 1 : 0, q = r == 2 ? 1 : 2;
+        g.ex[r] = c_mul(M[3 * r], c_sub(c_mul(M[3 * p + 1], M[3 * q + 2]), c_mul(M[3 * q + 1], M[3 * p + 2])));
+    }
+    grp_sync();
+    const cx87 det = c_add(c_sub(g.ex[0], g.ex[1]), g.ex[2]);
+    grp_sync();
+    // products the eigenvectors share: lane 0 h10 h02, lane 1 h21 h10, lane 2 h12 h20
+    {
+        const int i0 = r == 0 ? 3 : (r == 1 ? 7 : 5), i1 = r == 0 ? 2 : (r == 1 ? 3 : 6);
+        g.ex[r] = c_mul(M[i0], M[i1]);
+    }
+    grp_sync();
+    const cx87 h10h02 = g.ex[0], h21h10 = g.ex[1], h12h20 = g.ex[2];
+    const cx87 a = c_neg(tr);                                                           // fr.py:204
+    const cx87 b = c_scale(x_div(one, two), c_sub(c_mul(tr, tr), tr2));                 // fr.py:205
+    const cx87 c = c_neg(det);                                                          // fr.py:206
+    const cx87 a2 = c_mul(a, a);
+    const cx87 Q = c_scale(x_div(one, nine), c_sub(a2, c_scale(three, b)));             // fr.py:208
+    const cx87 R = c_scale(x_div(one, x_from(54.0)),
+                           c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
+    const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
+    const cx87 sq = c_sqrt_pos(Q);
+    const cx87 m2sq = c_scale(x_neg(two), sq);
+    const cx87 third_a = c_scale(x_div(one, three), a);
+    const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
+    const x87 twopi = x_mul(two, pi);
+    // eigenvalue r: theta, theta - 2 pi, theta + 2 pi  (fr.py:212-214)
+    x87 are = theta.re;
+    if (r == 1) are = x_sub(theta.re, twopi);
+    if (r == 2) are = x_add(theta.re, twopi);
+    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(are, theta.im), three))), third_a);
+    // eigenvector r (fr.py:216-236)
+    const cx87 A = c_sub(c_mul(M[5], c_sub(M[0], E)), h10h02);
+    const cx87 B = c_sub(c_mul(M[6], c_sub(M[4], E)), h21h10);
+    const cx87 C = c_sub(c_mul(M[3], c_sub(M[8], E)), h12h20);
+    const cx87 AB = c_mul(A, B), AC = c_mul(A, C), BC = c_mul(B, C);
+    const x87 ab = c_abs(AB), ac = c_abs(AC), bc = c_abs(BC);
+    const x87 N = x_sqrt(x_add(x_add(x_mul(ab, ab), x_mul(ac, ac)), x_mul(bc, bc)));   // fr.py:228-230
+    const cx87 x0 = c_div_real(c_mul(c_conj(B), C), N);                                 // fr.py:232-236
+    const cx87 x1 = c_div_real(AC, N);
+    const cx87 x2 = c_div_real(AB, N);
+    grp_sync();                                                                         // every lane is done with H
+    M[0 + r] = x0; M[3 + r] = x1; M[6 + r] = x2;                                        // column r of X
+    grp_sync();
+    // f = |X X^+| (fr.py:489): lane 0 -> f00, f01; lane 1 -> f02, f11; lane 2 -> f12, f22
+    {
+        x87* exx = reinterpret_cast<x87*>(g.ex);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = 2 * r + e;                                                  // 0..5 = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            const int i = idx < 3 ? 0 : (idx < 5 ? 1 : 2);
+            const int j = idx < 3 ? idx : (idx < 5 ? idx - 2 : 2);
+            cx87 sacc = c_mul(M[3 * i + 0], c_conj(M[3 * j + 0]));
+            sacc = c_add(sacc, c_mul(M[3 * i + 1], c_conj(M[3 * j + 1])));
+            sacc = c_add(sacc, c_mul(M[3 * i + 2], c_conj(M[3 * j + 2])));
+            exx[idx] = c_abs(sacc);
+        }
+    }
+    grp_sync();
+    double res;
+    {
+        const x87* exx = reinterpret_cast<const x87*>(g.ex);
+        const x87 f00 = exx[0], f01 = exx[1], f02 = exx[2], f11 = exx[3], f12 = exx[4], f22 = exx[5];
+        const x87 trf = x_add(x_add(f00, f11), f22);
+        const x87 sum = x_add(x_add(x_add(x_add(f00, f01), x_add(f02, f01)), x_add(x_add(f11, f12), x_add(f02, f12))), f22);
+        const double rt = fabs(x_to_double(x_sub(trf, three))), rs = fabs(x_to_double(x_sub(sum, three)));
+        res = rt > rs ? rt : rs;
+        if (!(res == res) || !(rt == rt) || !(rs == rs)) res = INFINITY;
+    }
+    grp_sync();                                                                         // M and ex are free again
+    return res;
+}
+
+// Three lanes = one walker at a time.  A group fetches a walker from the queue (one atomic per wave and round, shared out by
+// rank among the groups that need one), builds its Hamiltonian terms, then takes its undecided bins from the highest energy
 // down -- one bin per round of the wave -- until one fails (the walker is non-unitary: fr.py:398-399 raises on the first
 // failing energy) or none is left; then it fetches the next walker.  Every wave leaves when the queue is exhausted and all its
-// lanes have finished their walker: the exit condition is reached whatever the other waves do.
-__global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
+// groups have finished their walker: the exit condition is reached whatever the other waves do.
+__global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                            const double* __restrict__ theta, int layout, int64_t n,
                                                            double* __restrict__ lnprob, int32_t* __restrict__ status,
                                                            GfArbQueue* __restrict__ uq, GfUniQueue* __restrict__ wq, unsigned int* __restrict__ seen)
 {
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
-    const int lane = threadIdx.x & 63;
-    cx87 hsm[3][3], hnp[3][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / GRP;
+    const bool active = grp < GRP_PER_WAVE;                             // lane 63 has no group
+    Grp g;
+    {
+        double* base = lds + ((size_t)wave * GRP_PER_WAVE + (active ? grp : 0)) * GRP_DOUBLES;
+        g.M = reinterpret_cast<cx87*>(base);
+        g.ex = reinterpret_cast<cx87*>(base + 36);
+        g.r = lane - grp * GRP;
+    }
+    cx87 hs[3], hn[3];
     unsigned long long mask = 0ull;
     int64_t wi = -1;
-    bool exhausted = false;                                             // this lane found the queue empty
+    bool exhausted = !active;                                           // this group found the queue empty
     for (;;) {
         const bool need = !exhausted && mask == 0ull;
-        const unsigned long long nb = __ballot(need);
+        const unsigned long long nb = __ballot(need && g.r == 0);       // one request per group
         if (nb != 0ull) {
             unsigned int base = 0;
             const int leader = __ffsll((long long)nb) - 1;
             if (lane == leader) base = atomicAdd(&uq->head, (unsigned int)__popcll(nb));
             base = (unsigned int)__shfl((int)base, leader);
             if (need) {
-                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << lane) - 1ull));
+                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
                 if (idx < count) {
                     const GfArbItem it = uq->items[idx];
                     wi = (int64_t)it.walker;
                     mask = wi < n ? it.mask : 0ull;
-                    if (mask != 0ull) walker_terms(*cp, *tbp, theta, layout, n, wi, hsm, hnp);
+                    if (mask != 0ull) grp_walker_terms(g, *cp, *tbp, theta, layout, n, wi, hs, hn);
                 } else {
                     exhausted = true;
                 }
@@ -129,10 +390,12 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
         if (mask != 0ull) {
             const int k = 63 - __clzll((long long)mask);                // the highest undecided energy first: the likeliest to fail
             mask &= ~(1ull << k);
-            const double r = walker_bin_residual(hsm, hnp, tbp->inv2e[k], tbp->epow[k]);
-            if (!(r < 1e-7)) {                                          // fr.py:493-494 (NaN raises too)
-                status[wi] = ST_NON_UNITARY;
-                if (lnprob) lnprob[wi] = __longlong_as_double(0x7ff8000000000000LL);
+            const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+            if (!(res < 1e-7)) {                                        // fr.py:493-494 (NaN raises too)
+                if (g.r == 0) {
+                    status[wi] = ST_NON_UNITARY;
+                    if (lnprob) lnprob[wi] = __longlong_as_double(0x7ff8000000000000LL);
+                }
                 mask = 0ull;                                            // the reference has raised: the other bins never run
             }
         }
@@ -163,7 +426,54 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_resolve(const GfCommon* __res
     }
 }
 
+// ---- test hooks (tests/test_gpu_unitarity_r3.py): the residual of explicit (walker, bin) pairs by the serial chain of
+// gf_x87.hpp, one lane per pair -- the statement the host build checks against the CPU's x87 unit -- and by the three-lane
+// distribution above.  They must agree bit for bit.
+__global__ __launch_bounds__(64) void k_uni_debug_serial(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
+                                                         const double* __restrict__ theta, int layout, int64_t n,
+                                                         const int64_t* __restrict__ walkers, const int32_t* __restrict__ bins, int64_t npairs,
+                                                         double* __restrict__ out)
+{
+    for (int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x; t < npairs; t += (int64_t)gridDim.x * 64) {
+        cx87 hsm[3][3], hnp[3][3];
+        walker_terms(*cp, *tbp, theta, layout, n, walkers[t], hsm, hnp);
+        out[t] = walker_bin_residual(hsm, hnp, tbp->inv2e[bins[t]], tbp->epow[bins[t]]);
+    }
+}
+
+__global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
+                                                               const double* __restrict__ theta, int layout, int64_t n,
+                                                               const int64_t* __restrict__ walkers, const int32_t* __restrict__ bins, int64_t npairs,
+                                                               double* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / GRP;
+    if (grp >= GRP_PER_WAVE) return;
+    Grp g;
+    double* base = lds + ((size_t)wave * GRP_PER_WAVE + grp) * GRP_DOUBLES;
+    g.M = reinterpret_cast<cx87*>(base);
+    g.ex = reinterpret_cast<cx87*>(base + 36);
+    g.r = lane - grp * GRP;
+    const int64_t groups = (int64_t)gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE;
+    for (int64_t t = ((int64_t)blockIdx.x * (UNI_BLOCK / 64) + wave) * GRP_PER_WAVE + grp; t < npairs; t += groups) {
+        cx87 hs[3], hn[3];
+        grp_walker_terms(g, *cp, *tbp, theta, layout, n, walkers[t], hs, hn);
+        const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[bins[t]], tbp->epow[bins[t]]);
+        if (g.r == 0) out[t] = res;
+    }
+}
+
 }  // namespace
+
+// test hook: residuals of `npairs` explicit (walker, bin) pairs; which = 0 serial chain, 1 three-lane groups
+hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, const int64_t* walkers,
+                               const int32_t* bins, int64_t npairs, int which, double* out, hipStream_t s)
+{
+    if (which == 0) hipLaunchKernelGGL(k_uni_debug_serial, dim3(512), dim3(64), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out);
+    else hipLaunchKernelGGL(k_uni_debug_group, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out);
+    return hipGetLastError();
+}
 
 // The grid.  The chain keeps its 3x3 complex matrices in scratch (~2 KB per lane): a grid that fills the GPU asks the
 // runtime for ~0.5 GB of scratch, more than a queue retains, so that EVERY launch would pay an allocation (~30 us
@@ -180,9 +490,10 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
         const int64_t last = (int64_t)__atomic_load_n(seen, __ATOMIC_RELAXED);     // 0xffffffff: nothing seen yet
         expect = 2 * last < max_items ? 2 * last : max_items;
     }
-    // lanes fetch their walkers dynamically, several each: half as many lanes as walkers expected, at most GF_UNI_BLOCKS_PER_CU
-    // resident blocks per CU
-    int64_t blocks = (expect / 2 + UNI_BLOCK - 1) / UNI_BLOCK;
+    // three lanes per walker, 21 walkers per wave at a time; the groups fetch their walkers dynamically, so any grid is correct:
+    // one group per expected walker up to what is resident at once
+    constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
+    int64_t blocks = (expect + per_block - 1) / per_block;
     const int64_t cap = (int64_t)cus * GF_UNI_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     // A floor under the grid: a queue that fills up unannounced -- the first batch of a scan that enters the failing region --

@@ -158,19 +158,27 @@ GFX_HD inline dd dd_sqrt(dd a)
 }
 
 // ---- rounding to a 64-bit significand, ties to even ---------------------------------------------------
+// Branch-free since round 3: every + - * of the chain ends here, and the early returns of the first version (zero / inf / NaN,
+// out of the emulated range) put two or three divergent branches into each of them.  The general path is computed always and
+// the special cases are selected at the end; the results are unchanged bit for bit (tests/test_x87_emulation.py).
 GFX_HD inline x87 round64(dd v)
 {
-    x87 r = {v.hi, 0.0};
-    if (v.hi == 0.0 || !(fabs(v.hi) <= 1.7976931348623157e308)) return r;      // zero, inf, NaN
     const int64_t b = x_bits(v.hi);
     int e = (int)((b >> 52) & 0x7ff) - 1023;
     // the value's own binade: a negative tail under a power of two lies in the binade below
-    if ((b & 0xfffffffffffffLL) == 0 && v.lo != 0.0 && ((v.lo < 0.0) != (v.hi < 0.0))) e -= 1;
-    if (e < -1000) { r.lo = v.lo; return r; }                                    // out of the emulated range: keep the tail
-    // q = 2^(e-63) is the unit in the last place; adding 1.5 * 2^52 q rounds the tail to a multiple of q, ties to even
-    const double c = 1.5 * x_from_bits((int64_t)(e - 11 + 1023) << 52);
+    const bool below = ((b & 0xfffffffffffffLL) == 0) & (v.lo != 0.0) & ((v.lo < 0.0) != (v.hi < 0.0));
+    e -= below ? 1 : 0;
+    // q = 2^(e-63) is the unit in the last place; adding c = 1.5 * 2^52 q = 1.5 * 2^(e-11) rounds the tail to a multiple of q,
+    // ties to even.  c's bit pattern directly: exponent field e - 11 + 1023, top mantissa bit set
+    const double c = x_from_bits(((int64_t)(e + 1012) << 52) | 0x0008000000000000LL);
     const double lr = (v.lo + c) - c;
-    quick_two_sum(v.hi, lr, r.hi, r.lo);
+    const double hs = v.hi + lr;
+    const double ls = lr - (hs - v.hi);                                          // quick_two_sum(v.hi, lr)
+    const bool special = (v.hi == 0.0) | !(fabs(v.hi) <= 1.7976931348623157e308);    // zero, inf, NaN: (hi, 0)
+    const bool tiny = e < -1000;                                                 // out of the emulated range: keep the tail
+    x87 r;
+    r.hi = (special | tiny) ? v.hi : hs;
+    r.lo = special ? 0.0 : (tiny ? v.lo : ls);
     return r;
 }
 
@@ -195,9 +203,32 @@ GFX_HD inline x87 x_scale2(x87 a, double p2) { x87 r = {a.hi * p2, a.lo * p2}; r
 #define GFX_PIO2_2 6.123233995736766e-17
 #define GFX_PIO2_3 (-1.4973849048591698e-33)
 
-// sin and cos of a double-double, |x| < ~1e4
+// 1 / n! to double-double, n = 0 .. 29 (mpmath, 200 bits)
+struct ddc { double hi, lo; };
+#define GFX_INV_FACT_TABLE                                                                                         \
+    {1.0, 0.0}, {1.0, 0.0}, {0.5, 0.0}, {0.16666666666666666, 9.25185853854297e-18},                               \
+    {0.041666666666666664, 2.3129646346357427e-18}, {0.008333333333333333, 1.1564823173178714e-19},               \
+    {0.001388888888888889, -5.300543954373577e-20}, {0.0001984126984126984, 1.7209558293420705e-22},              \
+    {2.48015873015873e-05, 2.1511947866775882e-23}, {2.7557319223985893e-06, -1.858393274046472e-22},             \
+    {2.755731922398589e-07, 2.3767714622250297e-23}, {2.505210838544172e-08, -1.448814070935912e-24},             \
+    {2.08767569878681e-09, -1.20734505911326e-25}, {1.6059043836821613e-10, 1.2585294588752098e-26},              \
+    {1.1470745597729725e-11, 2.0655512752830745e-28}, {7.647163731819816e-13, 7.03872877733453e-30},              \
+    {4.779477332387385e-14, 4.399205485834081e-31}, {2.8114572543455206e-15, 1.6508842730861433e-31},             \
+    {1.5619206968586225e-16, 1.1910679660273754e-32}, {8.22063524662433e-18, 2.2141894119604265e-34},             \
+    {4.110317623312165e-19, 1.4412973378659527e-36}, {1.9572941063391263e-20, -1.3643503830087908e-36},           \
+    {8.896791392450574e-22, -7.911402614872376e-38}, {3.868170170630684e-23, -8.843177655482344e-40},             \
+    {1.6117375710961184e-24, -3.6846573564509766e-41}, {6.446950284384474e-26, -1.9330404233703465e-42},          \
+    {2.4795962632247976e-27, -1.2953730964765229e-43}, {9.183689863795546e-29, 1.4303150396787322e-45},           \
+    {3.279889237069838e-30, 1.5117542744029879e-46}, {1.1309962886447716e-31, 1.0498015412959506e-47}
+
+// sin and cos of a double-double, |x| < ~1e4, to ~2^-102.  Round 3: the Maclaurin series by Horner's rule with the
+// reciprocal factorials as double-double constants (round 2 divided every term by its index pair: two double-double
+// divisions per order, 14 orders -- 2 100 instructions a call, and the chain makes eleven calls per (walker, bin) when the
+// mixing angles are sampled).  The orders whose terms lie below 2^-52 of the leading one are summed in plain fp64 first:
+// their rounding errors are below 2^-104 of the result.  |r| <= pi/4 + eps after the reduction; r^30 / 30! < 2^-117.
 GFX_HD GFX_BIG void dd_sincos(dd x, dd& sn, dd& cs)
 {
+    static const ddc F[30] = {GFX_INV_FACT_TABLE};
     const double kf = nearbyint(x.hi * 0.6366197723675814);
     dd r = x;
     if (kf != 0.0) {
@@ -208,22 +239,32 @@ GFX_HD GFX_BIG void dd_sincos(dd x, dd& sn, dd& cs)
         r = dd_sub(r, dd_norm(p, e));
         r = dd_sub(r, dd_from(kf * GFX_PIO2_3));
     }
-    const dd r2 = dd_mul(r, r);
-    // Taylor series; |r| <= pi/4 + eps: the term of order 29 is below 2^-106
-    dd s = r, c = dd_from(1.0), ts = r, tc = dd_from(1.0);
-    for (int n = 1; n <= 14; ++n) {
-        tc = dd_div_d(dd_mul(tc, r2), (double)((2 * n - 1) * (2 * n)));
-        ts = dd_div_d(dd_mul(ts, r2), (double)((2 * n) * (2 * n + 1)));
-        if (n & 1) { c = dd_sub(c, tc); s = dd_sub(s, ts); }
-        else       { c = dd_add(c, tc); s = dd_add(s, ts); }
+    const dd t = dd_mul(r, r);
+    // sin r = r S(t),  S = sum_k (-1)^k t^k / (2k+1)!,  k = 0 .. 14;   cos r = C(t),  C = sum_k (-1)^k t^k / (2k)!,  k = 0 .. 14
+    // fp64 tails: S from k = 8 (t^8 / 17! < 2^-54), C from k = 9 (t^9 / 18! < 2^-58)
+    double ts = F[29].hi, tc = -F[28].hi;
+    GFX_ROLLED
+    for (int k = 13; k >= 8; --k) ts = x_fma(ts, t.hi, (k & 1) ? -F[2 * k + 1].hi : F[2 * k + 1].hi);
+    tc = x_fma(tc, t.hi, F[26].hi);                                            // k = 13
+    GFX_ROLLED
+    for (int k = 12; k >= 9; --k) tc = x_fma(tc, t.hi, (k & 1) ? -F[2 * k].hi : F[2 * k].hi);
+    dd s = dd_from(ts), c = dd_from(tc);
+    GFX_ROLLED
+    for (int k = 8; k >= 0; --k) {
+        const ddc fc = F[2 * k];
+        const dd ck = {(k & 1) ? -fc.hi : fc.hi, (k & 1) ? -fc.lo : fc.lo};
+        c = dd_add(dd_mul(c, t), ck);
+        if (k < 8) {
+            const ddc fs = F[2 * k + 1];
+            const dd sk = {(k & 1) ? -fs.hi : fs.hi, (k & 1) ? -fs.lo : fs.lo};
+            s = dd_add(dd_mul(s, t), sk);
+        }
     }
+    s = dd_mul(s, r);
     const int q = (int)((long long)kf & 3);
-    switch (q) {
-    case 0: sn = s; cs = c; break;
-    case 1: sn = c; cs = dd_neg(s); break;
-    case 2: sn = dd_neg(s); cs = dd_neg(c); break;
-    default: sn = dd_neg(c); cs = s; break;
-    }
+    const dd ns = dd_neg(s), nc = dd_neg(c);
+    sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? ns : nc));
+    cs = q == 0 ? c : (q == 1 ? ns : (q == 2 ? nc : s));
 }
 
 // asin for |t| <= ~0.75: one Newton step on sin from the fp64 value (error e -> e^2 tan / 2)
@@ -275,16 +316,23 @@ GFX_HD inline dd dd_acos(dd x)      // x in [-1, 1]
 GFX_HD inline double cr_pow10(double x)
 {
     if (!(fabs(x) < 300.0)) return pow(10.0, x);
+    static const ddc F[30] = {GFX_INV_FACT_TABLE};
     const dd L = {3.321928094887362, 1.661617516973592e-16};          // log2(10)
     const dd LN2 = {0.6931471805599453, 2.3190468138462996e-17};
     const dd y = dd_mul_d(L, x);
     const double n = nearbyint(y.hi);
     const dd f = dd_add(y, dd_from(-n));                              // [-1/2, 1/2]
-    const dd z = dd_mul(f, LN2);
-    dd sum = dd_from(1.0), term = dd_from(1.0);
-    for (int k = 1; k <= 26; ++k) {
-        term = dd_div_d(dd_mul(term, z), (double)k);
-        sum = dd_add(sum, term);
+    const dd z = dd_mul(f, LN2);                                      // |z| <= 0.3466
+    // exp z = sum z^k / k!, k = 0 .. 23 (z^24 / 24! < 2^-115): Horner's rule, the orders from 12 on (z^12 / 12! < 2^-47) in fp64
+    double tail = F[23].hi;
+    GFX_ROLLED
+    for (int k = 22; k >= 12; --k) tail = x_fma(tail, z.hi, F[k].hi);
+    dd sum = dd_from(tail);
+    GFX_ROLLED
+    for (int k = 11; k >= 0; --k) {
+        const ddc fk = F[k];
+        const dd ck = {fk.hi, fk.lo};
+        sum = dd_add(dd_mul(sum, z), ck);
     }
     return ldexp(sum.hi, (int)n);                                     // sum.hi = fl(sum): the nearest double
 }

@@ -89,6 +89,20 @@ int x87t_funcs(uint64_t seed, int n, int64_t* exact, int64_t* off1, int64_t* wor
     return 0;
 }
 
+// the emulated functions' results as (hi, lo) pairs, for comparison with correctly rounded values computed elsewhere
+// (tests/test_x87_emulation.py: mpmath, rounded to 64 bits): out = sin hi, sin lo, cos hi, cos lo, asin hi, asin lo, acos hi, acos lo
+void x87t_eval(double hi, double lo, double* out)
+{
+    const x87 a = {hi, lo};
+    x87 sn, cs;
+    x_sincos(a, sn, cs);
+    out[0] = sn.hi; out[1] = sn.lo; out[2] = cs.hi; out[3] = cs.lo;
+    const bool in = fabs(hi) <= 1.0;
+    const x87 as = in ? x_asin(a) : x_from(0.0), ac = in ? x_acos(a) : x_from(0.0);
+    out[4] = as.hi; out[5] = as.lo; out[6] = ac.hi; out[7] = ac.lo;
+}
+double x87t_pow10_value(double x) { return cr_pow10(x); }
+
 // 10^x: calls (out of n, x uniform in [lo, hi]) on which cr_pow10 and libm's pow disagree
 int x87t_pow10(uint64_t seed, int n, double lo, double hi)
 {

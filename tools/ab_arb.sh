@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of libgolemhip.so variants (tools/build_variants.sh) on the arbitration path: tools/ab_arb.sh base v1 v2 ...
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+for v in "$@"; do
+  if [ $v = base ]; then unset GOLEMHIP_LIB; else export GOLEMHIP_LIB=$PWD/variants/$v.so; fi
+  python tools/arb_probe.py 2>&1 | head -3 | cut -c1-175 | sed "s/^/$v | /"
+done; done
