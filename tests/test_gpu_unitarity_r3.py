@@ -75,8 +75,9 @@ def test_three_lane_chain_equals_the_serial_chain_bit_for_bit(dim, tex, twelve, 
     # the residual is amplified rounding noise: where the emulated asin / acos / sin / cos differ from libm's in a last bit
     # (faithful, not correctly rounded) it changes by a factor of order one -- never by decades
     big = want > 1e-12
-    off = np.abs(np.log10(got[big] / want[big]))
-    assert np.mean(off < 0.5) > 0.99 and off.max() < 1.5, (np.mean(off < 0.5), off.max())
+    if big.any():                                                   # (random NP angles keep every residual below 1e-12)
+        off = np.abs(np.log10(got[big] / want[big]))
+        assert np.mean(off < 0.5) > 0.99 and off.max() < 1.5, (np.mean(off < 0.5), off.max())
     near = want > 1e-9
     if near.any():
         assert np.abs(np.log10(got[near] / want[near])).max() < 0.6
