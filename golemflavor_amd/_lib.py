@@ -111,7 +111,6 @@ SIGNATURES = {
     "gf_host_prepare": (C.c_int, [_vp, C.c_size_t]),
     "gf_sampler_set_stream_ids": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "gf_sampler_get_chain_device": (C.c_int, [_vp, _vp, _vp]),
-    "gf_sampler_pending": (C.c_int, [_vp, C.POINTER(C.c_uint32), _dp, C.c_uint32]),
     "gf_sampler_postprocess_device": (C.c_int, [_vp, C.POINTER(_vp), _vp, _vp]),
     "gf_sampler_postprocess_rows_device": (C.c_int, [_vp, C.POINTER(_vp), _vp]),
     "gf_sampler_postprocess_rows": (C.c_int, [_vp, C.POINTER(_vp), _dp]),

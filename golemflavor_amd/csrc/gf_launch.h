@@ -36,3 +36,37 @@ hipError_t gf_launch_cube_to_theta(const GfCommon& c, int nscan, const int32_t* 
 // test hook (gf_unitarity.hip): emulated-x87 residuals of explicit (walker, bin) pairs; which = 0 serial chain, 1 three-lane groups
 hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, const int64_t* walkers,
                                const int32_t* bins, int64_t npairs, int which, double* out, hipStream_t s);
+
+// ---- the device sampler's settlement of undecided proposals (gf_sampler.hip -> gf_unitarity.hip) ---------------------------
+// Step counters of the device sampler (live on the device so that a captured hipGraph can be replayed with constant kernel
+// arguments; see gf_sampler.hip)
+struct GfStepState {
+    uint64_t iteration_base;  // Philox counter word of step_offset 0
+    int64_t run_step_base;    // steps of the current gf_sampler_run call done before step_offset 0
+    int64_t store_base;       // chain slot of the run's first stored step
+    int32_t store;            // this run stores at all
+    int32_t thin;
+};
+constexpr int GF_PEND_STRIDE = GF_MAX_DIM + 2;     // a deferred proposal: theta [GF_MAX_DIM] | lnprob of the proposal | ln(z^(ndim-1) / u)
+// A proposal of the stretch move whose unitarity verdict (fr.py:461-499) the in-kernel tiers cannot settle is NOT decided by the
+// half-step kernel: the kernel parks it -- row t = chain * (nwalkers / 2) + k of `pend_rows`, item {t, undecided bins} in `pq` --
+// and k_stretch_settle, next in stream order, takes the exact (emulated x87) verdict and completes the walker's update: reject
+// and count if the reference would have raised, else the usual accept test; it also writes the walker's stored sample.
+struct GfSettleArgs {
+    const GfStepState* state;
+    GfArbQueue* pq;             // capacity nchains * nwalkers / 2
+    const double* pend_rows;    // [nchains * nwalkers / 2][GF_PEND_STRIDE]
+    double* pos;                // [nchains][nwalkers][ndim]
+    double* lnp;                // [nchains][nwalkers]
+    uint32_t* naccept;          // [nchains][nwalkers]
+    uint32_t* flags;            // [0]: proposals the reference would have raised on
+    double* chain;              // [nchains][nstore_cap][nwalkers][ndim] or null
+    double* lnp_chain;
+    int64_t nstore_cap;
+    int32_t nchains, nwalkers, half, step_offset, ndim;
+    const GfCommon* commons;    // [nchains] (multi != 0) or [1]
+    const GfBsm* const* tbs;    // [nchains] (multi != 0), else null
+    const GfBsm* tb;            // multi == 0
+    int32_t multi;
+};
+hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t s);

@@ -47,6 +47,7 @@ constexpr int UNI_BLOCK = 128;
 #define GF_UNI_BLOCKS_PER_CU (GF_UNI_WAVES * 4 * 64 / UNI_BLOCK)    // what is resident at once: later blocks would find the queue empty
 #endif
 
+// `ndim`: the row stride of an AoS block (the sampler's parked proposals are rows of GF_PEND_STRIDE doubles)
 __device__ inline double row_value(const double* __restrict__ theta, int layout, int64_t n, int ndim, int64_t i, int col)
 {
     return layout == 0 ? theta[i * ndim + col] : theta[(int64_t)col * n + i];
@@ -188,9 +189,9 @@ __device__ __forceinline__ void grp_sandwich_row(const Grp& g, const cx87 urow[3
 
 // the walker's part of fr.py:380-399: row r of hsm and hnp
 __device__ __forceinline__ void grp_walker_terms(const Grp& g, const GfCommon& c, const GfBsm& tb, const double* __restrict__ theta,
-                                                            int layout, int64_t n, int64_t i, cx87 hs[3], cx87 hn[3])
+                                                            int layout, int64_t n, int64_t i, cx87 hs[3], cx87 hn[3], int stride = 0)
 {
-    const int ndim = c.ndim;
+    const int ndim = stride ? stride : c.ndim;                          // row stride of the block
     cx87 urow[3];
     if (c.idx_sm[0] >= 0) {                                             // fr.py:425-431: all six from theta, or none
         double ang[4];
@@ -426,6 +427,107 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
     }
 }
 
+// The device sampler's parked proposals (gf_sampler.hip, gf_launch.h GfSettleArgs): the same three-lane arbitration, and at
+// the end of a walker -- one bin failed, or all of them passed -- lane 0 of the group completes that walker's half-step exactly
+// as the half-step kernel does for the proposals it settles itself: a proposal the reference would have raised on is rejected
+// and counted, any other goes through the accept test ln(z^(ndim-1) / u) > lnp(s) - lnp(q); the stored sample is written.
+__global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(const GfSettleArgs s)
+{
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
+    GfArbQueue* __restrict__ uq = s.pq;
+    const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
+    if (count != 0u) {                                                  // (uniform: the common case leaves at once)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / GRP;
+    const bool active = grp < GRP_PER_WAVE;
+    Grp g;
+    {
+        double* base = lds + ((size_t)wave * GRP_PER_WAVE + (active ? grp : 0)) * GRP_DOUBLES;
+        g.M = reinterpret_cast<cx87*>(base);
+        g.ex = reinterpret_cast<cx87*>(base + 36);
+        g.r = lane - grp * GRP;
+    }
+    const int ndim = s.ndim, nhalf = s.nwalkers / 2;
+    const int64_t nprop = (int64_t)s.nchains * nhalf;
+    const int64_t run_step = s.state->run_step_base + s.step_offset;
+    const int thin = s.state->thin;
+    const bool store_now = s.state->store != 0 && s.chain != nullptr && (run_step % thin) == 0;
+    const int64_t store_index = s.state->store_base + (run_step + thin - 1) / thin;
+    cx87 hs[3], hn[3];
+    unsigned long long mask = 0ull;
+    int64_t t = -1;
+    int chain = 0;
+    bool exhausted = !active, failed = false;
+    for (;;) {
+        const bool need = !exhausted && mask == 0ull;
+        const unsigned long long nb = __ballot(need && g.r == 0);
+        if (nb != 0ull) {
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)nb) - 1;
+            if (lane == leader) base = atomicAdd(&uq->head, (unsigned int)__popcll(nb));
+            base = (unsigned int)__shfl((int)base, leader);
+            if (need) {
+                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
+                if (idx < count) {
+                    const GfArbItem it = uq->items[idx];
+                    t = (int64_t)it.walker;
+                    mask = t < nprop ? it.mask : 0ull;
+                    failed = false;
+                    if (mask != 0ull) {
+                        chain = (int)(t / nhalf);
+                        const GfCommon& c = s.commons[s.multi ? chain : 0];
+                        const GfBsm& tb = *(s.multi ? s.tbs[chain] : s.tb);
+                        grp_walker_terms(g, c, tb, s.pend_rows, 0, nprop, t, hs, hn, GF_PEND_STRIDE);
+                    }
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(!exhausted) == 0ull) break;
+        if (mask != 0ull) {
+            const GfBsm* tbp = s.multi ? s.tbs[chain] : s.tb;
+            const int k = 63 - __clzll((long long)mask);
+            mask &= ~(1ull << k);
+            const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+            if (!(res < 1e-7)) { failed = true; mask = 0ull; }          // fr.py:493-494: the reference raises
+            if (mask == 0ull && g.r == 0) {
+                // this walker's verdict is in: finish its half-step (gf_sampler.hip stretch_body, after proposal_lnprob)
+                const double* row = s.pend_rows + (size_t)t * GF_PEND_STRIDE;
+                const int kk = (int)(t - (int64_t)chain * nhalf);
+                const int w = s.half * nhalf + kk;
+                const int64_t wi = (int64_t)chain * s.nwalkers + w;
+                const double lnq = row[GF_MAX_DIM], lhs = row[GF_MAX_DIM + 1];
+                const double lnk = s.lnp[wi];
+                bool accept = lhs > lnk - lnq;
+                if (failed) { accept = false; atomicAdd(s.flags, 1u); }
+                double* pw = s.pos + wi * ndim;
+                if (accept) {
+                    for (int d = 0; d < ndim; ++d) pw[d] = row[d];
+                    s.lnp[wi] = lnq;
+                    s.naccept[wi] += 1u;
+                }
+                if (store_now) {
+                    double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w) * ndim;
+                    for (int d = 0; d < ndim; ++d) dst[d] = accept ? row[d] : pw[d];
+                    if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
+                }
+            }
+        }
+    }
+    }   // count != 0
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&uq->done, 1u) == gridDim.x - 1) {                // the last block re-arms the queue for the next half-step
+            uq->count = 0;
+            uq->done = 0;
+            uq->head = 0;
+            __threadfence();
+        }
+    }
+}
+
 // ---- test hooks (tests/test_gpu_unitarity_r3.py): the residual of explicit (walker, bin) pairs by the serial chain of
 // gf_x87.hpp, one lane per pair -- the statement the host build checks against the CPU's x87 unit -- and by the three-lane
 // distribution above.  They must agree bit for bit.
@@ -465,6 +567,20 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* _
 }
 
 }  // namespace
+
+// the sampler's settle step; the count is on the device, the groups fetch dynamically: a modest fixed grid (it sits in a captured
+// graph and runs after every half-step, almost always on an empty queue -- where its cost is the launch)
+hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t s)
+{
+    constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
+    const int64_t nprop = (int64_t)a.nchains * (a.nwalkers / 2);
+    int64_t blocks = (nprop + per_block - 1) / per_block;
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    (void)cus;
+    hipLaunchKernelGGL(k_stretch_settle, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
 
 // test hook: residuals of `npairs` explicit (walker, bin) pairs; which = 0 serial chain, 1 three-lane groups
 hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, const double* theta, int layout, int64_t n, const int64_t* walkers,

@@ -258,7 +258,6 @@ class DeviceEnsembleSampler:
 
     def reset(self):
         self._lib.check(self._L.gf_sampler_reset(self._h), "gf_sampler_reset")
-        self._pend_seen, self._pend_bad = 0, 0
 
     def run_mcmc(self, pos0, N, thin=1, storechain=True):
         """Advance N steps (asynchronous launches, then one sync); returns (pos, lnprob, None)."""
@@ -304,34 +303,14 @@ class DeviceEnsembleSampler:
             for _ in range(m):
                 yield pos, lnp, None
 
-    PEND_CAP = 16384
-
     def _count_nonunitary(self):
-        """Non-unitary proposals since the last reset.  The kernels settle the verdict of almost every proposal
-        themselves (csrc/gf_bsm_device.hpp, tiers 1-2); the few they cannot were evaluated as unitary and logged, and
-        get their exact verdict here through the bulk path (x87-faithful arbitration)."""
-        C = self._C
-        n = (C.c_uint32 * 1)()
+        """Non-unitary proposals since the last reset (device counter).  Every proposal's verdict is settled on the device
+        BEFORE its accept step: almost all by the half-step kernel itself (csrc/gf_bsm_device.hpp, tiers 1-2), the rest by
+        k_stretch_settle, which replays the reference's arithmetic in emulated x87 (csrc/gf_unitarity.hip) -- so the count is
+        exact and a rejected-as-non-unitary proposal never enters the chain."""
+        n = (self._C.c_uint32 * 1)()
         self._lib.check(self._L.gf_sampler_get_chain(self._h, None, None, None, n), "gf_sampler_get_chain")
-        bad = int(n[0])
-        cnt = C.c_uint32(0)
-        self._lib.check(self._L.gf_sampler_pending(self._h, C.byref(cnt), None, 0), "gf_sampler_pending")
-        seen = getattr(self, "_pend_seen", 0)
-        if cnt.value < seen:                                   # the sampler was reset
-            seen, self._pend_bad = 0, 0
-        if cnt.value > seen and seen < self.PEND_CAP:
-            m = min(cnt.value, self.PEND_CAP)
-            rows = np.empty((m, 1 + self._lib.GF_MAX_DIM))
-            self._lib.check(self._L.gf_sampler_pending(self._h, C.byref(cnt), rows.ctypes.data_as(self._lib._dp), m),
-                            "gf_sampler_pending")
-            new = rows[seen:m]
-            for ch in np.unique(new[:, 0]).astype(int):
-                model = self.models[ch] if self.models is not None else self.model
-                th = np.ascontiguousarray(new[new[:, 0] == ch][:, 1:1 + self.dim])
-                st = model.lnprob(th)[1]
-                self._pend_bad = getattr(self, "_pend_bad", 0) + int(np.sum(st == self._lib.GF_ST_NON_UNITARY))
-            self._pend_seen = cnt.value
-        return bad + getattr(self, "_pend_bad", 0)
+        return int(n[0])
 
     @property
     def nonunitary_proposals(self):

@@ -153,6 +153,10 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         sampler.reset()
         sampler.run_mcmc(None, nsteps)
         PHASES["sampling"] = time.perf_counter() - t0
+        # proposals of the stored run the reference would have died on (fr.py:493-498): rejected on the device, counted here
+        LAST_NONUNITARY.clear()
+        LAST_NONUNITARY.update({"nonunitary_proposals_rejected": int(sampler.nonunitary_proposals),
+                                "settled": "on the device, before the accept step (k_stretch_settle)"})
         t0 = time.perf_counter()
         if gather is not None:
             out = gather.run(sampler, jobs, order, len(points))

@@ -226,12 +226,9 @@ int64_t gf_sampler_nstored(const gf_sampler* s);
 int64_t gf_sampler_iterations(const gf_sampler* s);
 int gf_sampler_get_state(gf_sampler* s, double* pos, double* lnprob);
 /* chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers],
- * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on; NULL = skip */
+ * naccepted [nchains][nwalkers], nonunitary[1] = proposals the reference would have raised on (fr.py:493-498; they were
+ * rejected: every proposal's unitarity verdict is settled on the device before its accept step, ABI 3); NULL = skip */
 int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uint32_t* naccepted, uint32_t* nonunitary);
-/* Proposals since the last reset whose unitarity verdict (fr.py:461-499) the in-kernel estimate could not settle: they were
- * evaluated as unitary and logged.  *count = how many; rows [min(count, cap, 16384)][1 + GF_MAX_DIM] = chain index, theta
- * (NULL: count only).  Their exact verdict comes from gf_lnprob_batch with a status array. */
-int gf_sampler_pending(gf_sampler* s, uint32_t* count, double* rows, uint32_t cap);
 /* the stored chain packed into caller-owned DEVICE buffers (what gf_comm_allgather sends); NULL = skip; synchronous */
 int gf_sampler_get_chain_device(gf_sampler* s, double* d_chain, double* d_lnprob_chain);
 /* mean [nchains][nstored][ndim]: ensemble mean of every stored step, the series behind sampler.acor

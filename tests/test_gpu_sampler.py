@@ -13,14 +13,15 @@ from golemflavor_amd.enums import Texture
 pytestmark = pytest.mark.gpu
 
 
-def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0):
+def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0, lnprob=None):
     """The published stretch move, written out in numpy with the sampler's random stream: one
     Philox4x32-10 block per (walker slot, half-step), u1 53 bits, partner and u3 32 bits."""
     nchains, nwalkers, ndim = p0.shape
     nhalf = nwalkers // 2
     pos = p0.copy()
     oms = list(om) if isinstance(om, (list, tuple)) else [om] * nchains      # one posterior per chain, or one for all
-    lnp = np.stack([oracle.lnprob_batch(oms[c], pos[c]) for c in range(nchains)])
+    lnprob = lnprob or oracle.lnprob_batch
+    lnp = np.stack([lnprob(oms[c], pos[c]) for c in range(nchains)])
     chain = np.empty((nchains, nsteps, nwalkers, ndim))
     nacc = np.zeros((nchains, nwalkers), dtype=int)
     key = (seed & 0xffffffff, seed >> 32)
@@ -41,7 +42,7 @@ def _reference_stretch(oracle, om, p0, nsteps, seed, a=2.0):
                     zz[k] = zr * zr / a
                     cj, sk = pos[c, cbase + j], pos[c, half * nhalf + k]
                     q[k] = cj - zz[k] * (cj - sk)
-                lq = oracle.lnprob_batch(oms[c], q)
+                lq = lnprob(oms[c], q)
                 lk = lnp[c, half * nhalf:(half + 1) * nhalf]
                 with np.errstate(all="ignore"):
                     acc = np.log(zz ** (ndim - 1) / u3) > lk - lq
@@ -487,39 +488,85 @@ def test_multinest_style_cube_adapter(golden, oracle):
 
 
 
-def test_bsm_sampler_unitarity_through_the_failing_region():
+def test_bsm_sampler_unitarity_through_the_failing_region(oracle):
     """A 12-column chain of texture OEU seeded across the top of its scale range, where the reference's unitarity assert
-    fires (fr.py:461-499).  The stretch kernels settle most proposals in-kernel (SM-weight bound, fp64 estimate); the ones
-    they cannot are evaluated as unitary, logged, and judged exactly afterwards through the bulk path.  `raise` (the
-    reference's behaviour): the run dies; `-inf`: it completes and reports how many proposals a reference run would have
-    died on -- at least the ones the estimate condemned outright."""
-    import ctypes as C
+    fires (fr.py:461-499).  Every proposal's verdict is settled ON THE DEVICE before its accept step: most by the half-step
+    kernel itself (SM-weight bound, fp64 estimate), the undecided ones by k_stretch_settle, which replays the reference's
+    arithmetic in emulated x87.  So with on_nonunitary='-inf' the chain is the chain of a host-driven run in which those
+    proposals score -inf.  Checked against the numpy stretch move on the same Philox stream, evaluated by the ORACLE with the
+    oracle's verdicts, proposal by proposal (the proposals bit-identical to the device's: its fused multiply-add is restated
+    exactly): every accept decision agrees, except where the oracle's residual lies within half a decade of 1e-7 -- there the
+    reference's own verdict is a property of its libm's last bits, the device's decision is adopted and
+    the comparison goes on.  The number of non-unitary proposals agrees up to those.  `raise` (the reference's behaviour):
+    the run dies."""
+    from fractions import Fraction
     inj = fr_utils.fr_to_angles((1, 1, 1))
     asimov, ps = Cf.fr_paramsets(6, inj)
-    args = bsm_args(6, Texture.OEU, (1 / 3, 2 / 3, 0.))
+    src = (1 / 3, 2 / 3, 0.)
+    args = bsm_args(6, Texture.OEU, src)
     rng = np.random.default_rng(4)
     box = np.array(ps.seeds, dtype=float)
-    p0 = rng.uniform(box[:, 0], box[:, 1], size=(64, 12))
-    p0[:, 11] = rng.uniform(-40.0, -30.0, 64)
+    nw, nsteps, seed, a, ndim = 64, 40, 11, 2.0, 12
+    nhalf = nw // 2
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nw, ndim))
+    p0[:, 11] = rng.uniform(-40.0, -30.0, nw)
     f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.3, on_nonunitary="-inf")
-    smp = mcmc_utils.DeviceEnsembleSampler(64, 12, f, seed=11)
-    smp.run_mcmc(p0, 40)
-    n = (C.c_uint32 * 1)()
-    _lib.check(smp._L.gf_sampler_get_chain(smp._h, None, None, None, n), "flags")
-    cnt = C.c_uint32(0)
-    _lib.check(smp._L.gf_sampler_pending(smp._h, C.byref(cnt), None, 0), "pending")
-    assert n[0] > 0 and cnt.value > 0                       # both kinds occur in this region
-    assert smp.nonunitary_proposals >= n[0]
-    # the logged proposals: their exact verdict through the bulk path is what _check_flags added
-    rows = np.empty((min(cnt.value, 16384), 1 + _lib.GF_MAX_DIM))
-    _lib.check(smp._L.gf_sampler_pending(smp._h, C.byref(cnt), rows.ctypes.data_as(_lib._dp), len(rows)), "pending rows")
-    st = f.model.lnprob(np.ascontiguousarray(rows[:, 1:13]))[1]
-    assert np.all(rows[:, 0] == 0) and smp.nonunitary_proposals == n[0] + int(np.sum(st == _lib.GF_ST_NON_UNITARY))
+    smp = mcmc_utils.DeviceEnsembleSampler(nw, ndim, f, seed=seed)
+    smp.run_mcmc(p0, nsteps)
+    got = smp.chain.transpose(1, 0, 2)                                   # (step, walker, dim)
+    got_lnp = smp.lnprobability.T
+    nbad_dev = smp.nonunitary_proposals
+    om = oracle.make_model(ps, "BSM_GAUSS", texture="OEU", dimension=6, binning=BIN_EDGES, source_ratio=src,
+                           bestfit_fr=fr_utils.angles_to_fr(inj), smearing=0.3)
+    pos = p0.copy()
+    lp, st = oracle.lnprob_batch(om, pos, want_status=True)
+    lnp = np.where(st == oracle.NON_UNITARY, -np.inf, lp)                # a start the reference would have died on
+    nbad, nband, nforced, naccept = int(np.sum(st == oracle.NON_UNITARY)), 0, 0, 0
+    key = (seed & 0xffffffff, seed >> 32)
+    for it in range(nsteps):
+        for half in (0, 1):
+            t = 2 * it + half
+            cbase = (1 - half) * nhalf
+            q = np.empty((nhalf, ndim)); zz = np.empty(nhalf); u3 = np.empty(nhalf)
+            for k in range(nhalf):
+                r = oracle.philox4x32_10((k, 0, t & 0xffffffff, t >> 32), key)
+                u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
+                j = (r[2] * nhalf) >> 32
+                u3[k] = (r[3] + 0.5) / 4294967296.0
+                zr = (a - 1.0) * u1 + 1.0
+                zz[k] = zr * zr / a
+                cj, sk = pos[cbase + j], pos[half * nhalf + k]
+                # q = fma(-z, c_j - s_k, c_j), rounded once, as the kernel forms it
+                q[k] = [float(Fraction(-zz[k]) * Fraction(float(cj[d] - sk[d])) + Fraction(float(cj[d]))) for d in range(ndim)]
+            lq, sq = oracle.lnprob_batch(om, q, want_status=True)
+            res = oracle.unitarity_residual_batch(om, q)
+            band = (sq != oracle.OUT_OF_PRIOR) & (res > 10 ** -7.25) & (res < 10 ** -6.75)
+            lq = np.where(sq == oracle.NON_UNITARY, -np.inf, lq)
+            nbad += int(np.sum(sq == oracle.NON_UNITARY))
+            nband += int(band.sum())
+            idx = np.arange(half * nhalf, (half + 1) * nhalf)
+            with np.errstate(all="ignore"):
+                acc = np.log(zz ** (ndim - 1) / u3) > lnp[idx] - lq
+            want = np.where(acc[:, None], q, pos[idx])
+            dev = got[it][idx]
+            differ = np.abs(dev - want).max(axis=1) > 1e-12
+            assert not np.any(differ & ~band), "step %d half %d: decisions differ outside the band (residuals %s)" % (it, half, res[differ & ~band])
+            nforced += int(differ.sum())
+            pos[idx] = dev                                                # (= want wherever they agree)
+            lnp[idx] = np.where(differ, got_lnp[it][idx], np.where(acc, lq, lnp[idx]))
+            naccept += int(acc.sum())
+    assert nbad > 500 and naccept > 200                                  # the chain does live in the failing region, and moves
+    assert nforced <= nband and abs(nbad_dev - nbad) <= nband, (nbad_dev, nbad, nband, nforced)
+    assert np.allclose(smp.state[1], lnp, rtol=1e-10)
+    # no stored sample is one the reference would have died on, except a start position that never moved (or a band case)
+    st = oracle.lnprob_batch(om, got.reshape(-1, ndim), want_status=True)[1].reshape(nsteps, nw)
+    moved = np.any(got != p0[None], axis=2)
+    assert np.sum((st == oracle.NON_UNITARY) & moved) <= nforced * nsteps
     smp.close()
     g = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.3)              # on_nonunitary="raise", the reference's behaviour
-    smp = mcmc_utils.DeviceEnsembleSampler(64, 12, g, seed=11)
+    smp = mcmc_utils.DeviceEnsembleSampler(nw, ndim, g, seed=seed)
     with pytest.raises(AssertionError, match="not unitary"):
-        smp.run_mcmc(p0, 40)
+        smp.run_mcmc(p0, nsteps)
     smp.close()
     f.close()
     g.close()
