@@ -56,6 +56,7 @@ struct GfSettleArgs {
     const GfStepState* state;
     GfArbQueue* pq;             // capacity nchains * nwalkers / 2
     const double* pend_rows;    // [nchains * nwalkers / 2][GF_PEND_STRIDE]
+    unsigned int* ctl;          // [nchains * nwalkers / 2][2]: parts of the walker that have finished, one of them failed (zero between uses)
     double* pos;                // [nchains][nwalkers][ndim]
     double* lnp;                // [nchains][nwalkers]
     uint32_t* naccept;          // [nchains][nwalkers]

@@ -520,6 +520,7 @@ struct gf_sampler {
     uint32_t* d_flags = nullptr;
     GfArbQueue* d_pq = nullptr;         // BSM posteriors: proposals parked for k_stretch_settle (capacity: one half-step's proposals)
     double* d_pend_rows = nullptr;      // [nchains * nwalkers / 2][GF_PEND_STRIDE]
+    unsigned int* d_pend_ctl = nullptr; // [nchains * nwalkers / 2][2]: k_stretch_settle's per-walker counters, zero between uses
     double* d_chain = nullptr;
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
@@ -594,6 +595,8 @@ int gf_sampler_create(gf_model* m, int nchains, int nwalkers, uint64_t seed, dou
         const size_t nprop = (size_t)nchains * (nwalkers / 2);
         e = hipMalloc((void**)&s->d_pq, sizeof(GfArbQueue) + sizeof(GfArbItem) * nprop);
         if (e == hipSuccess) e = hipMalloc((void**)&s->d_pend_rows, sizeof(double) * nprop * GF_PEND_STRIDE);
+        if (e == hipSuccess) e = hipMalloc((void**)&s->d_pend_ctl, sizeof(unsigned int) * 2 * nprop);
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_pend_ctl, 0, sizeof(unsigned int) * 2 * nprop, (hipStream_t)stream);
         if (e == hipSuccess) {
             GfArbQueue ah;
             std::memset(&ah, 0, sizeof(ah));
@@ -634,6 +637,7 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_pq) (void)hipFree(s->d_pq);
     if (s->d_pend_rows) (void)hipFree(s->d_pend_rows);
+    if (s->d_pend_ctl) (void)hipFree(s->d_pend_ctl);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->d_chain) (void)hipFree(s->d_chain);
@@ -822,7 +826,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     a.stream_ids = s->d_stream_ids;
     a.lpw = lanes_per_walker(c->mode, (int64_t)s->nchains * (s->nwalkers / 2), s->nbins_max, s->cus);
     GfSettleArgs sa;
-    sa.state = s->d_state; sa.pq = s->d_pq; sa.pend_rows = s->d_pend_rows; sa.pos = s->d_pos; sa.lnp = s->d_lnp; sa.naccept = s->d_naccept;
+    sa.state = s->d_state; sa.pq = s->d_pq; sa.pend_rows = s->d_pend_rows; sa.ctl = s->d_pend_ctl; sa.pos = s->d_pos; sa.lnp = s->d_lnp; sa.naccept = s->d_naccept;
     sa.flags = s->d_flags; sa.chain = a.chain; sa.lnp_chain = a.lnp_chain; sa.nstore_cap = s->nstore_cap; sa.nchains = s->nchains;
     sa.nwalkers = s->nwalkers; sa.half = 0; sa.step_offset = 0; sa.ndim = s->ndim; sa.commons = s->d_commons; sa.tbs = s->d_tbs; sa.tb = tb;
     sa.multi = s->models ? 1 : 0;

@@ -254,7 +254,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     for (int j = 0; j < 3; ++j) M[3 * r + j] = c_add(c_scale(xp, hs[j]), c_scale(xe, hn[j]));      // fr.py:386, 394-395
     grp_sync();
     // cardano_residual
-    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0), one = x_from(1.0);
+    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0);
     const cx87 tr = c_add(c_add(M[0], M[4]), M[8]);
     // tr H^2: lane r forms (H^2)_rr
     {
@@ -282,16 +282,16 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     grp_sync();
     const cx87 h10h02 = g.ex[0], h21h10 = g.ex[1], h12h20 = g.ex[2];
     const cx87 a = c_neg(tr);                                                           // fr.py:204
-    const cx87 b = c_scale(x_div(one, two), c_sub(c_mul(tr, tr), tr2));                 // fr.py:205
+    const cx87 b = c_scale(GFX_X87_HALF, c_sub(c_mul(tr, tr), tr2));                    // fr.py:205
     const cx87 c = c_neg(det);                                                          // fr.py:206
     const cx87 a2 = c_mul(a, a);
-    const cx87 Q = c_scale(x_div(one, nine), c_sub(a2, c_scale(three, b)));             // fr.py:208
-    const cx87 R = c_scale(x_div(one, x_from(54.0)),
+    const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
+    const cx87 R = c_scale(GFX_X87_54TH,
                            c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
     const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
     const cx87 sq = c_sqrt_pos(Q);
     const cx87 m2sq = c_scale(x_neg(two), sq);
-    const cx87 third_a = c_scale(x_div(one, three), a);
+    const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
     const x87 twopi = x_mul(two, pi);
     // eigenvalue r: theta, theta - 2 pi, theta + 2 pi  (fr.py:212-214)
@@ -341,6 +341,35 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     return res;
 }
 
+// Fan-out of a short queue.  A walker's bins are evaluated one after the other by one group -- right for throughput, but a
+// queue with fewer walkers than the grid has groups leaves most of the GPU idle behind the critical path of the walker with
+// the most bins (nine bins: ~0.4 ms).  So with `count` walkers and `groups` groups in the grid every walker is cut into
+// F = min(GF_UNI_MAX_FANOUT, groups / count) parts: part j takes the walker's j-th, (j + F)-th, ... undecided bin, counted from
+// the highest energy, and builds the walker's terms itself (redundant work on otherwise idle lanes).  A long queue has F = 1.
+#ifndef GF_UNI_MAX_FANOUT
+#define GF_UNI_MAX_FANOUT 20
+#endif
+__device__ __forceinline__ unsigned int uni_fanout(unsigned int count, unsigned int groups)
+{
+    if (count == 0u) return 1u;
+    unsigned int f = groups / count;
+    f = f < 1u ? 1u : f;
+    return f > (unsigned int)GF_UNI_MAX_FANOUT ? (unsigned int)GF_UNI_MAX_FANOUT : f;
+}
+// the bins of `mask` whose rank from the top is part, part + fan, ...
+__device__ __forceinline__ unsigned long long uni_part_mask(unsigned long long mask, unsigned int part, unsigned int fan)
+{
+    if (fan <= 1u) return mask;
+    unsigned long long out = 0ull;
+    unsigned int ord = 0;
+    for (unsigned long long rest = mask; rest != 0ull; ++ord) {
+        const int k = 63 - __clzll((long long)rest);
+        rest &= ~(1ull << k);
+        if (ord % fan == part) out |= 1ull << k;
+    }
+    return out;
+}
+
 // Three lanes = one walker at a time.  A group fetches a walker from the queue (one atomic per wave and round, shared out by
 // rank among the groups that need one), builds its Hamiltonian terms, then takes its undecided bins from the highest energy
 // down -- one bin per round of the wave -- until one fails (the walker is non-unitary: fr.py:398-399 raises on the first
@@ -363,6 +392,8 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
         g.ex = reinterpret_cast<cx87*>(base + 36);
         g.r = lane - grp * GRP;
     }
+    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE);
+    const unsigned long long vcount = (unsigned long long)count * fan;  // (walker, part) items; count <= 2^23, fan <= 20
     cx87 hs[3], hn[3];
     unsigned long long mask = 0ull;
     int64_t wi = -1;
@@ -377,10 +408,10 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
             base = (unsigned int)__shfl((int)base, leader);
             if (need) {
                 const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
-                if (idx < count) {
-                    const GfArbItem it = uq->items[idx];
+                if (idx < vcount) {
+                    const GfArbItem it = uq->items[idx / fan];
                     wi = (int64_t)it.walker;
-                    mask = wi < n ? it.mask : 0ull;
+                    mask = wi < n ? uni_part_mask(it.mask, idx % fan, fan) : 0ull;
                     if (mask != 0ull) grp_walker_terms(g, *cp, *tbp, theta, layout, n, wi, hs, hn);
                 } else {
                     exhausted = true;
@@ -388,6 +419,7 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
             }
         }
         if (__ballot(!exhausted) == 0ull) break;                        // wave-uniform
+        if (fan > 1u && mask != 0ull && status[wi] == ST_NON_UNITARY) mask = 0ull;    // another part of this walker has failed already
         if (mask != 0ull) {
             const int k = 63 - __clzll((long long)mask);                // the highest undecided energy first: the likeliest to fail
             mask &= ~(1ull << k);
@@ -436,7 +468,11 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
     GfArbQueue* __restrict__ uq = s.pq;
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
-    if (count != 0u) {                                                  // (uniform: the common case leaves at once)
+    // nothing parked -- the usual case wherever a posterior keeps away from the failing region: nothing to settle and nothing to
+    // re-arm (count and head are zero already).  No block changes the queue before EVERY block has read the count: the re-arming
+    // below is done by the last block to arrive, so all blocks take the same branch here.
+    if (count == 0u && uq->overflow == 0u) return;
+    {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / GRP;
     const bool active = grp < GRP_PER_WAVE;
@@ -453,13 +489,19 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     const int thin = s.state->thin;
     const bool store_now = s.state->store != 0 && s.chain != nullptr && (run_step % thin) == 0;
     const int64_t store_index = s.state->store_base + (run_step + thin - 1) / thin;
+    // A half-step waits for this kernel, and a handful of parked proposals is the usual case: what counts is the critical path
+    // of ONE walker, so its bins are spread over as many groups as the grid has to spare (uni_fanout).  The last part of a
+    // walker to finish completes its update.
+    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE);
+    const unsigned long long vcount = (unsigned long long)count * fan;
     cx87 hs[3], hn[3];
     unsigned long long mask = 0ull;
     int64_t t = -1;
     int chain = 0;
-    bool exhausted = !active, failed = false;
+    unsigned int parts = 1;
+    bool exhausted = !active, failed = false, mine = false;             // mine: this group holds a part whose end it must report
     for (;;) {
-        const bool need = !exhausted && mask == 0ull;
+        const bool need = !exhausted && !mine;
         const unsigned long long nb = __ballot(need && g.r == 0);
         if (nb != 0ull) {
             unsigned int base = 0;
@@ -468,12 +510,16 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
             base = (unsigned int)__shfl((int)base, leader);
             if (need) {
                 const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
-                if (idx < count) {
-                    const GfArbItem it = uq->items[idx];
+                if (idx < vcount) {
+                    const GfArbItem it = uq->items[idx / fan];
                     t = (int64_t)it.walker;
-                    mask = t < nprop ? it.mask : 0ull;
+                    const unsigned int nbits = (unsigned int)__popcll(it.mask);
+                    parts = nbits < fan ? nbits : fan;
+                    const unsigned int part = idx % fan;
+                    mask = (t < nprop && part < parts) ? uni_part_mask(it.mask, part, fan) : 0ull;
                     failed = false;
-                    if (mask != 0ull) {
+                    mine = mask != 0ull;
+                    if (mine) {
                         chain = (int)(t / nhalf);
                         const GfCommon& c = s.commons[s.multi ? chain : 0];
                         const GfBsm& tb = *(s.multi ? s.tbs[chain] : s.tb);
@@ -484,38 +530,54 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                 }
             }
         }
-        if (__ballot(!exhausted) == 0ull) break;
-        if (mask != 0ull) {
-            const GfBsm* tbp = s.multi ? s.tbs[chain] : s.tb;
-            const int k = 63 - __clzll((long long)mask);
-            mask &= ~(1ull << k);
-            const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
-            if (!(res < 1e-7)) { failed = true; mask = 0ull; }          // fr.py:493-494: the reference raises
-            if (mask == 0ull && g.r == 0) {
-                // this walker's verdict is in: finish its half-step (gf_sampler.hip stretch_body, after proposal_lnprob)
-                const double* row = s.pend_rows + (size_t)t * GF_PEND_STRIDE;
-                const int kk = (int)(t - (int64_t)chain * nhalf);
-                const int w = s.half * nhalf + kk;
-                const int64_t wi = (int64_t)chain * s.nwalkers + w;
-                const double lnq = row[GF_MAX_DIM], lhs = row[GF_MAX_DIM + 1];
-                const double lnk = s.lnp[wi];
-                bool accept = lhs > lnk - lnq;
-                if (failed) { accept = false; atomicAdd(s.flags, 1u); }
-                double* pw = s.pos + wi * ndim;
-                if (accept) {
-                    for (int d = 0; d < ndim; ++d) pw[d] = row[d];
-                    s.lnp[wi] = lnq;
-                    s.naccept[wi] += 1u;
-                }
-                if (store_now) {
-                    double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w) * ndim;
-                    for (int d = 0; d < ndim; ++d) dst[d] = accept ? row[d] : pw[d];
-                    if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
+        if (__ballot(!exhausted || mine) == 0ull) break;
+        if (mine) {
+            if (mask != 0ull && fan > 1u && __atomic_load_n(&s.ctl[2 * t + 1], __ATOMIC_RELAXED) != 0u) mask = 0ull;   // another part failed
+            if (mask != 0ull) {
+                const GfBsm* tbp = s.multi ? s.tbs[chain] : s.tb;
+                const int k = 63 - __clzll((long long)mask);
+                mask &= ~(1ull << k);
+                const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+                if (!(res < 1e-7)) { failed = true; mask = 0ull; }      // fr.py:493-494: the reference raises
+            }
+            if (mask == 0ull) {
+                mine = false;
+                if (g.r == 0) {
+                    // report this part; the last part of the walker to report completes the walker's half-step
+                    // (gf_sampler.hip stretch_body, after proposal_lnprob)
+                    if (failed) atomicOr(&s.ctl[2 * t + 1], 1u);
+                    __threadfence();
+                    const unsigned int before = atomicAdd(&s.ctl[2 * t], 1u);
+                    if (before == parts - 1u) {
+                        __threadfence();
+                        const bool bad = atomicOr(&s.ctl[2 * t + 1], 0u) != 0u;
+                        s.ctl[2 * t] = 0u;                              // zero between uses
+                        s.ctl[2 * t + 1] = 0u;
+                        const double* row = s.pend_rows + (size_t)t * GF_PEND_STRIDE;
+                        const int kk = (int)(t - (int64_t)chain * nhalf);
+                        const int w = s.half * nhalf + kk;
+                        const int64_t wi = (int64_t)chain * s.nwalkers + w;
+                        const double lnq = row[GF_MAX_DIM], lhs = row[GF_MAX_DIM + 1];
+                        const double lnk = s.lnp[wi];
+                        bool accept = lhs > lnk - lnq;
+                        if (bad) { accept = false; atomicAdd(s.flags, 1u); }
+                        double* pw = s.pos + wi * ndim;
+                        if (accept) {
+                            for (int d = 0; d < ndim; ++d) pw[d] = row[d];
+                            s.lnp[wi] = lnq;
+                            s.naccept[wi] += 1u;
+                        }
+                        if (store_now) {
+                            double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w) * ndim;
+                            for (int d = 0; d < ndim; ++d) dst[d] = accept ? row[d] : pw[d];
+                            if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
+                        }
+                    }
                 }
             }
         }
     }
-    }   // count != 0
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -523,6 +585,7 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
             uq->count = 0;
             uq->done = 0;
             uq->head = 0;
+            uq->overflow = 0;
             __threadfence();
         }
     }
@@ -574,10 +637,10 @@ hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t 
 {
     constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
     const int64_t nprop = (int64_t)a.nchains * (a.nwalkers / 2);
-    int64_t blocks = (nprop + per_block - 1) / per_block;
-    if (blocks > 64) blocks = 64;
+    // enough groups to spread a short queue's walkers over (fan-out); on an empty queue every block returns after one load
+    int64_t blocks = (nprop * GF_UNI_MAX_FANOUT + per_block - 1) / per_block;
+    if (blocks > 2 * cus) blocks = 2 * cus;
     if (blocks < 1) blocks = 1;
-    (void)cus;
     hipLaunchKernelGGL(k_stretch_settle, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, a);
     return hipGetLastError();
 }
@@ -609,7 +672,8 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
     // three lanes per walker, 21 walkers per wave at a time; the groups fetch their walkers dynamically, so any grid is correct:
     // one group per expected walker up to what is resident at once
     constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
-    int64_t blocks = (expect + per_block - 1) / per_block;
+    // (eight groups per expected walker: a short queue is spread over idle groups, uni_fanout)
+    int64_t blocks = (expect * 8 + per_block - 1) / per_block;
     const int64_t cap = (int64_t)cus * GF_UNI_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     // A floor under the grid: a queue that fills up unannounced -- the first batch of a scan that enters the failing region --

@@ -57,6 +57,23 @@
 #define GFX_ROLLED
 #endif
 
+// A/B switches for the arbitration kernels (tools/build_variants.sh): the complex / scalar primitives out of line
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GFX87_CMUL_NOINLINE)
+#define GFX_CMUL __attribute__((noinline))
+#else
+#define GFX_CMUL inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GFX87_CADD_NOINLINE)
+#define GFX_CADD __attribute__((noinline))
+#else
+#define GFX_CADD inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GFX87_X_NOINLINE)
+#define GFX_XOP __attribute__((noinline))
+#else
+#define GFX_XOP inline
+#endif
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #elif defined(__GNUC__)
@@ -190,9 +207,9 @@ GFX_HD inline double x_to_double(x87 a) { return a.hi + a.lo; }
 GFX_HD inline bool x_is_zero(x87 a) { return a.hi == 0.0; }
 GFX_HD inline bool x_ge(x87 a, x87 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
 
-GFX_HD inline x87 x_add(x87 a, x87 b) { return round64(dd_add(as_dd(a), as_dd(b))); }
+GFX_HD GFX_XOP x87 x_add(x87 a, x87 b) { return round64(dd_add(as_dd(a), as_dd(b))); }
 GFX_HD inline x87 x_sub(x87 a, x87 b) { return x_add(a, x_neg(b)); }      // dd_sub is dd_add of the negation: the same operations
-GFX_HD inline x87 x_mul(x87 a, x87 b) { return round64(dd_mul(as_dd(a), as_dd(b))); }
+GFX_HD GFX_XOP x87 x_mul(x87 a, x87 b) { return round64(dd_mul(as_dd(a), as_dd(b))); }
 GFX_HD GFX_BIG x87 x_div(x87 a, x87 b) { return round64(dd_div(as_dd(a), as_dd(b))); }
 GFX_HD GFX_BIG x87 x_sqrt(x87 a) { return round64(dd_sqrt(as_dd(a))); }
 GFX_HD inline x87 x_scale2(x87 a, double p2) { x87 r = {a.hi * p2, a.lo * p2}; return r; }    // exact: p2 a power of two
@@ -353,19 +370,26 @@ GFX_HD inline x87 x_hypot(x87 a, x87 b)
     return round64(dd_sqrt(dd_add(dd_mul(da, da), dd_mul(db, db))));
 }
 
+// 1/2, 1/3, 1/9, 1/54 rounded to a 64-bit significand: what fr.py:205-209's `1./2`, `/ 3.`, `(1./9)`, `(1./54)` are in np.float128
+// -- four divisions per energy bin that are the same every time (checked against x_div: tests/test_x87_emulation.py)
+#define GFX_X87_HALF x87{0.5, 0.0}
+#define GFX_X87_THIRD x87{0.3333333333333333, 1.8512752095189988e-17}
+#define GFX_X87_NINTH x87{0.1111111111111111, 6.1663998560113065e-18}
+#define GFX_X87_54TH x87{0.018518518518518517, 1.0282979979667206e-18}
+
 // ---- complex arithmetic the way numpy does it for np.complex256 ------------------------------------------
 GFX_HD inline cx87 c_make(x87 re, x87 im) { cx87 r = {re, im}; return r; }
 GFX_HD inline cx87 c_zero() { cx87 r = {{0.0, 0.0}, {0.0, 0.0}}; return r; }
-GFX_HD inline cx87 c_add(cx87 a, cx87 b) { return c_make(x_add(a.re, b.re), x_add(a.im, b.im)); }
-GFX_HD inline cx87 c_sub(cx87 a, cx87 b) { return c_make(x_sub(a.re, b.re), x_sub(a.im, b.im)); }
+GFX_HD GFX_CADD cx87 c_add(cx87 a, cx87 b) { return c_make(x_add(a.re, b.re), x_add(a.im, b.im)); }
+GFX_HD GFX_CADD cx87 c_sub(cx87 a, cx87 b) { return c_make(x_sub(a.re, b.re), x_sub(a.im, b.im)); }
 GFX_HD inline cx87 c_neg(cx87 a) { return c_make(x_neg(a.re), x_neg(a.im)); }
 GFX_HD inline cx87 c_conj(cx87 a) { return c_make(a.re, x_neg(a.im)); }
-GFX_HD inline cx87 c_mul(cx87 a, cx87 b)
+GFX_HD GFX_CMUL cx87 c_mul(cx87 a, cx87 b)
 {
     return c_make(x_sub(x_mul(a.re, b.re), x_mul(a.im, b.im)), x_add(x_mul(a.re, b.im), x_mul(a.im, b.re)));
 }
 // real * complex: numpy promotes the real to (r, 0); the products with the zero are exact, so this is a scaling
-GFX_HD inline cx87 c_scale(x87 r, cx87 a) { return c_make(x_mul(r, a.re), x_mul(r, a.im)); }
+GFX_HD GFX_CADD cx87 c_scale(x87 r, cx87 a) { return c_make(x_mul(r, a.re), x_mul(r, a.im)); }
 // numpy's complex division (Smith)
 GFX_HD inline cx87 c_div(cx87 a, cx87 b)
 {
@@ -480,7 +504,7 @@ GFX_HD inline void sandwich(const cx87 u[3][3], double w1, double w2, cx87 h[3][
 // fr.py:170-237 cardano_eqn followed by fr.py:489-494: returns max(|tr f - 3|, |sum f - 3|); NaN -> +inf
 GFX_HD inline double cardano_residual(const cx87 h[3][3])
 {
-    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0), one = x_from(1.0);
+    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0);
     const cx87 tr = c_add(c_add(h[0][0], h[1][1]), h[2][2]);
     cx87 tr2 = c_zero();
     {
@@ -495,19 +519,19 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
         tr2 = c_add(c_add(d[0], d[1]), d[2]);
     }
     const cx87 a = c_neg(tr);                                                           // fr.py:204
-    const cx87 b = c_scale(x_div(one, two), c_sub(c_mul(tr, tr), tr2));                 // fr.py:205
+    const cx87 b = c_scale(GFX_X87_HALF, c_sub(c_mul(tr, tr), tr2));                    // fr.py:205
     const cx87 det = c_add(c_sub(c_mul(h[0][0], c_sub(c_mul(h[1][1], h[2][2]), c_mul(h[2][1], h[1][2]))),
                                  c_mul(h[1][0], c_sub(c_mul(h[0][1], h[2][2]), c_mul(h[2][1], h[0][2])))),
                            c_mul(h[2][0], c_sub(c_mul(h[0][1], h[1][2]), c_mul(h[1][1], h[0][2]))));   // fr.py:77-79
     const cx87 c = c_neg(det);                                                          // fr.py:206
     const cx87 a2 = c_mul(a, a);
-    const cx87 Q = c_scale(x_div(one, nine), c_sub(a2, c_scale(three, b)));             // fr.py:208
-    const cx87 R = c_scale(x_div(one, x_from(54.0)),
+    const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
+    const cx87 R = c_scale(GFX_X87_54TH,
                            c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
     const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
     const cx87 sq = c_sqrt_pos(Q);
     const cx87 m2sq = c_scale(x_neg(two), sq);
-    const cx87 third_a = c_scale(x_div(one, three), a);
+    const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
     const x87 twopi = x_mul(two, pi);
     cx87 E[3];

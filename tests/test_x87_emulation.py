@@ -99,6 +99,12 @@ def test_functions_are_correctly_rounded_against_mpmath(x87lib):
     assert bad == {"sin": 0, "cos": 0, "asin": 0, "acos": 0, "pow10": 0}, bad
 
 
+def test_reciprocal_constants_are_the_divisions_they_replace(x87lib):
+    """1/2, 1/3, 1/9, 1/54 as 64-bit-significand constants (fr.py:205-209's divisions of constants, four per energy bin) equal
+    the emulated divisions AND the CPU's own long-double quotients."""
+    assert x87lib.x87t_consts() == 0
+
+
 def test_pow10_is_libms(x87lib):
     """fr.py:380 np.power(10., logLam): the chain's one fp64 transcendental.  The emulation's correctly rounded 10^x
     equals libm's pow (correctly rounded on all but ~0.1 % of arguments) on >= 99.7 % of the scale range."""

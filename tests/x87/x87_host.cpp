@@ -102,6 +102,16 @@ void x87t_eval(double hi, double lo, double* out)
     out[4] = as.hi; out[5] = as.lo; out[6] = ac.hi; out[7] = ac.lo;
 }
 double x87t_pow10_value(double x) { return cr_pow10(x); }
+// the reciprocal constants of the header against the divisions they replace: number of mismatches
+int x87t_consts(void)
+{
+    const x87 one = x_from(1.0);
+    const x87 want[4] = {x_div(one, x_from(2.0)), x_div(one, x_from(3.0)), x_div(one, x_from(9.0)), x_div(one, x_from(54.0))};
+    const x87 have[4] = {GFX_X87_HALF, GFX_X87_THIRD, GFX_X87_NINTH, GFX_X87_54TH};
+    int bad = 0;
+    for (int i = 0; i < 4; ++i) bad += !(want[i].hi == have[i].hi && want[i].lo == have[i].lo) || !same(to_ld(have[i]), 1.0L / (ld)(i == 0 ? 2 : i == 1 ? 3 : i == 2 ? 9 : 54));
+    return bad;
+}
 
 // 10^x: calls (out of n, x uniform in [lo, hi]) on which cr_pow10 and libm's pow disagree
 int x87t_pow10(uint64_t seed, int n, double lo, double hi)
