@@ -25,6 +25,9 @@ def golden():
     # G11-G17 (second round): tests/golden/make_golden_r2.py
     with np.load(os.path.join(ROOT, "tests", "golden", "golden_r2.npz"), allow_pickle=False) as z:
         out.update({k: z[k] for k in z.files})
+    # round 3: the generating numpy's 10**logLam per row of G8, G9, G11-G14 (tests/golden/make_golden_r3.py)
+    with np.load(os.path.join(ROOT, "tests", "golden", "golden_r3.npz"), allow_pickle=False) as z:
+        out.update({k: z[k] for k in z.files if k.endswith("_sc2")})
     return out
 
 

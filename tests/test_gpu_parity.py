@@ -206,15 +206,13 @@ def test_docs_known_answers_on_the_gpu():
 
 
 # ---------------------------------------------------------------- BSM path
-def _status_must_agree(oracle, om, theta):
-    """Rows of a REFERENCE-generated fixture on which the stored verdict can be held against the device.  The
-    reference's assert (fr.py:493-494) fires on the rounding noise of its own 80-bit closed form, and that noise changes
-    by a factor of order one with the last bit of 10**logLam -- which the generating numpy computes with a vectorised
-    pow that is not libm's on ~5 % of arguments (test_oracle_golden.py G17).  The device (correctly rounded 10**x)
-    therefore reproduces the stored verdicts outside two decades around the threshold; against the oracle, which shares
-    its 10**x, the zone is half a decade (_status_must_agree_with_oracle)."""
-    r80 = oracle.unitarity_residual_batch(om, theta)
-    return (r80 < 1e-9) | (r80 > 1e-5)
+def _status_must_agree(oracle, om, theta, sc2_stored):
+    """Rows of a REFERENCE-generated fixture on which the stored verdict is held against the device: see
+    common.stored_verdict_zone -- half a decade around 1e-7 wherever the generating numpy's 10**logLam is libm's (~95 % of
+    the rows; round 3 stores that power per row, tests/golden/make_golden_r3.py), two decades on the rest."""
+    from common import stored_verdict_zone
+    must, res, same = stored_verdict_zone(oracle, om, theta, sc2_stored)
+    return must
 
 
 def _status_must_agree_with_oracle(r80):
@@ -252,7 +250,7 @@ def test_bsm_golden_flux_average(golden, oracle):
                     fr, st = m.propagate(th)
                 ref_st = golden["g8_status"][sel]
                 ok = ref_st == 0
-                clear = _status_must_agree(oracle, om, th)
+                clear = _status_must_agree(oracle, om, th, golden["g8_sc2"][sel])
                 assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[clear], (ref_st == 2)[clear])
                 n_flag += int(((st == _lib.GF_ST_NON_UNITARY) & (ref_st == 2)).sum())
                 worst_ref = max(worst_ref, np.abs(fr[ok] - golden["g8_fr"][sel][ok]).max())
@@ -274,7 +272,7 @@ def test_bsm_golden_lnprob_12dim(golden, oracle):
         with Model(desc) as m:
             lp, fr, st = m.lnprob(th, want_fr=True)
         ref, ref_st = golden["g9_lnprob"][sel], golden["g9_status"][sel]
-        clear = _status_must_agree(oracle, om, th) & (st != _lib.GF_ST_OUT_OF_PRIOR)
+        clear = _status_must_agree(oracle, om, th, golden["g9_sc2"][sel]) & (st != _lib.GF_ST_OUT_OF_PRIOR)
         assert np.array_equal((st == _lib.GF_ST_NON_UNITARY)[clear], (ref_st == 2)[clear])
         good = (ref_st == 0) & (st != _lib.GF_ST_NON_UNITARY)
         assert np.array_equal(np.isinf(lp[good]), np.isinf(ref[good]))

@@ -44,15 +44,24 @@ def _decided(r80, wide=None):
     return np.where(wide, (r80 < UNI_BAND_WIDE[0]) | (r80 > UNI_BAND_WIDE[1]), narrow)
 
 
-def _verdicts(st, r80, ref_st, evaluated):
+def _verdicts(st, r80, ref_st, evaluated, stored=None):
     """Unitarity verdict of the device on the evaluated rows: the oracle's (its residual `r80` against 1e-7, fr.py:493-494;
-    the oracle is the reference bit for bit given the same 10**logLam) outside the narrow band, and the reference's own
-    stored verdict outside the wide one."""
+    the oracle is the reference bit for bit given the same 10**logLam) outside the narrow band; and the reference's own STORED
+    verdict outside the narrow band as well wherever the generating numpy's 10**logLam is libm's, outside the wide one on the
+    rest (`stored` = (oracle, oracle model, theta, stored powers): common.stored_verdict_zone)."""
     flagged = st == _lib.GF_ST_NON_UNITARY
     dec = _decided(r80) & evaluated
     assert np.array_equal(flagged[dec], (r80 >= 1e-7)[dec])
-    wide = ((r80 < UNI_BAND_WIDE[0]) | (r80 > UNI_BAND_WIDE[1])) & evaluated
-    assert np.array_equal(flagged[wide], (ref_st == 2)[wide])
+    if stored is None:
+        wide = ((r80 < UNI_BAND_WIDE[0]) | (r80 > UNI_BAND_WIDE[1])) & evaluated
+        assert np.array_equal(flagged[wide], (ref_st == 2)[wide])
+        return
+    from common import stored_verdict_zone
+    must, res, same = stored_verdict_zone(*stored)
+    # given the stored power the oracle IS the reference: its verdict is the stored one on every evaluated row
+    assert np.array_equal((res >= 1e-7)[evaluated], (ref_st == 2)[evaluated])
+    must &= evaluated
+    assert np.array_equal(flagged[must], (ref_st == 2)[must])
 
 
 def _check_fr(fr, st, ref_fr, ref_st, exact, r80):
@@ -85,7 +94,7 @@ def test_bsm_golden_flux_average_dims_4_5_7_8(golden, oracle):
             fr, st = m.propagate(th)
         r80 = oracle.unitarity_residual_batch(om, th)
         ref_st = golden["g11_status"][sel]
-        _verdicts(st, r80, ref_st, np.ones(len(th), bool))
+        _verdicts(st, r80, ref_st, np.ones(len(th), bool), stored=(oracle, om, th, golden["g11_sc2"][sel]))
         g, c = _check_fr(fr, st, golden["g11_fr"][sel], ref_st, golden["g11_fr_exact"][sel], r80)
         ngood += g; nclean += c
         nflag += int(((st == _lib.GF_ST_NON_UNITARY) & (ref_st == 2)).sum())
@@ -109,7 +118,7 @@ def test_bsm_golden_lnprob_12dim_dims_4_5_7_8(golden, oracle):
         r80 = oracle.unitarity_residual_batch(om, th)
         inbox = st != _lib.GF_ST_OUT_OF_PRIOR
         assert np.array_equal(~inbox, ~np.isfinite(golden["g12_fr_exact"][sel][:, 0])) and np.isneginf(ref[~inbox]).all()
-        _verdicts(st, r80, ref_st, inbox)
+        _verdicts(st, r80, ref_st, inbox, stored=(oracle, om, th, golden["g12_sc2"][sel]))
         exact = golden["g12_fr_exact"][sel]
         has = inbox & np.isfinite(exact[:, 0])
         assert np.abs(fr[has] - exact[has]).max() <= EXACT_FR
@@ -140,7 +149,7 @@ def test_bsm_texture_none_golden(golden, oracle):
             fr, st = m.propagate(th)
         r80 = oracle.unitarity_residual_batch(om, th)
         ref_st = golden["g13_status"][sel]
-        _verdicts(st, r80, ref_st, np.ones(len(th), bool))
+        _verdicts(st, r80, ref_st, np.ones(len(th), bool), stored=(oracle, om, th, golden["g13_sc2"][sel]))
         g, c = _check_fr(fr, st, golden["g13_fr"][sel], ref_st, golden["g13_fr_exact"][sel], r80)
         ngood += g; nclean += c
     assert ngood >= 150 and nclean >= 60
@@ -160,7 +169,7 @@ def test_bsm_texture_none_golden(golden, oracle):
         r80 = oracle.unitarity_residual_batch(om, th)
         inbox = st != _lib.GF_ST_OUT_OF_PRIOR
         assert (~inbox).sum() == 1 and np.isneginf(lp[~inbox]).all() and np.isneginf(ref[~inbox]).all()
-        _verdicts(st, r80, ref_st, inbox)
+        _verdicts(st, r80, ref_st, inbox, stored=(oracle, om, th, golden["g14_sc2"][sel]))
         exact = golden["g14_fr_exact"][sel]
         has = inbox & np.isfinite(exact[:, 0])
         assert np.abs(fr[has] - exact[has]).max() <= EXACT_FR
@@ -271,7 +280,9 @@ def test_unitarity_verdict_through_the_transition(golden, oracle):
         ndec += int(dec.sum()); nband += int((~dec).sum())
         nagree_band += int((flagged == (ref_st[sel] == 2))[~dec].sum())
     assert ndec >= 700 and nband >= 5
-    assert nagree_band >= 0.6 * nband
+    # inside the band nothing is promised; what is observed (profiles/r03/verdicts_inside_the_band.txt): the device agrees with
+    # the stored verdict on every one of these rows too -- held here with one row of margin
+    assert nagree_band >= nband - 1, (nagree_band, nband)
 
 
 def test_deferred_tier2_equals_inline(oracle):

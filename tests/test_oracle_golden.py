@@ -298,3 +298,44 @@ def test_g16_chain_identifier(golden_meta):
                                   injected_ratio=it["injected_ratio"], data=DataType[it["data"]], texture=Texture[it["texture"]])
         assert mcmc.solve_ratio(it["source_ratio"]) == it["solve_ratio_src"], it
         assert mcmc.chain_identifier(args) == it["identifier"], it
+
+
+def test_stored_powers_make_the_oracle_the_reference_on_every_bsm_row(golden, oracle):
+    """golden_r3.npz stores, per row of G8, G9, G11-G14, the value the generating numpy gave 10**logLam (fr.py:380).  Fed that
+    power the oracle's unitarity verdict -- worst residual over the energy bins against 1e-7, fr.py:489-494 -- is the
+    reference's stored verdict on EVERY evaluated row of every set (1 558 rows, 47 of them raising): the assert's outcome is
+    pinned bit-tight, not to a band.  On 93 of the rows numpy's power is not libm's; none of those happens to sit close enough
+    to the threshold for the verdict to flip with libm's power (in G17's transition sweep some do) -- the tests of the device
+    (correctly rounded 10**x = libm's) keep the wide band on exactly those rows and the half-decade band on all others."""
+    import math
+    from test_oracle_golden import _mm_paramset as mm
+    total = raising = flips = differ = 0
+    for name in ("g8", "g9", "g11", "g12", "g13", "g14"):
+        rows, st, sc2 = golden[name + "_rows"], golden[name + "_status"], golden[name + "_sc2"]
+        assert sc2.shape == (len(rows),)
+        for r, s_ref, p in zip(rows, st, sc2):
+            if name in ("g8", "g11"):
+                dim, tex, src, th = int(r[0]), TEX_BY_VALUE[int(r[1])].name, golden[name + "_sources"][int(r[2])], r[3:]
+                ps = Cf.texture_paramset(dim)
+            elif name in ("g9", "g12"):
+                dim, tex, src, th = int(r[0]), TEX_BY_VALUE[int(r[1])].name, r[2:5], r[5:]
+                ps = Cf.fr_paramsets(dim, (0.4, 0.0))[1]
+            elif name == "g13":
+                dim, tex, src, th = int(r[0]), "NONE", golden["g13_sources"][int(r[1])], r[2:]
+                ps = mm(dim, False)
+            else:
+                dim, tex, src, th = int(r[0]), "NONE", r[1:4], r[4:]
+                ps = mm(dim, True)
+            box = np.array(ps.ranges, dtype=float)
+            if not np.all((th >= box[:, 0]) & (th <= box[:, 1])):
+                continue                                             # outside the prior box: the reference never evaluates it
+            om = oracle.make_model(ps, "BSM_GAUSS", texture=tex, dimension=dim, binning=BIN_EDGES, source_ratio=src)
+            res = oracle.unitarity_residual_batch(om, th[None], sc2=np.array([p]))[0]
+            assert (res >= 1e-7) == (s_ref == 2), (name, r, res)
+            total += 1
+            raising += int(s_ref == 2)
+            if math.pow(10., th[-1]) != p:
+                differ += 1
+                flips += int((oracle.unitarity_residual_batch(om, th[None])[0] >= 1e-7) != (s_ref == 2))
+    assert total >= 1500 and raising >= 40 and differ >= 60, (total, raising, differ)
+    print("rows %d, raising %d, power differs from libm's on %d, verdict flips with libm's power on %d" % (total, raising, differ, flips))
