@@ -341,8 +341,37 @@ def test_device_sampler_recovers_truncated_gaussian_priors():
 
 
 def test_mcmc_driver_device_resident(golden, capsys):
+    """mcmc.mcmc() with the reference's signature, device-resident and host-driven, on the notebook posterior.  Both are held
+    to the posterior's REFERENCE widths (a long device chain), not to each other: round 2's one-off failure of this test
+    (device std 0.062 against host std 0.110 on sin^4 phi_S) was one walker of the host run trapped in the posterior's
+    secondary mode at sin^4 phi_S -> 0, a pure nu_tau source -- lnprob -385 against -302, behind a valley of -450 that the
+    stretch move crosses only with z ~ 1/2; one walker in a hundred there turns 0.063 into sqrt(0.063^2 + 0.01 * 0.92^2) =
+    0.111 (profiles/r03/flaky_sampler_test_explained.txt).  Either sampler does that in ~2 % of runs; so the bulk is compared
+    with the reference and the trapped fraction is bounded separately."""
     asimov, ps = notebook_sets(golden)
     f = llh_utils.notebook_ln_prob(asimov, ps)
+    # reference widths: 2048 walkers, 1000 burn-in + 3000 steps thinned by 5 (the long-chain numbers of the profile file: rel 3 %)
+    rng = np.random.default_rng(5)
+    box = np.array(ps.seeds, dtype=float)
+    ref_s = mcmc_utils.DeviceEnsembleSampler(2048, 6, f, seed=3)
+    ref_s.run_mcmc(rng.uniform(box[:, 0], box[:, 1], size=(2048, 6)), 1000, storechain=False)
+    ref_s.reset()
+    ref_s.run_mcmc(None, 3000, thin=5)
+    ref = ref_s.flatchain
+    ref_s.close()
+    ref = ref[ref[:, 4] > 0.3]                                     # the bulk (a trapped walker sits at sin^4 phi_S < 0.01)
+    ref_mean, ref_std = ref.mean(axis=0), ref.std(axis=0)
+    assert np.allclose(ref_std, [0.0122, 0.0015, 0.0469, 1.3258, 0.0627, 0.0522], rtol=0.03)
+    assert np.allclose(ref_mean, [0.2998, 0.9564, 0.5816, 3.1432, 0.9223, 0.9362], atol=0.05 * ref_std)
+
+    def check(samples, label):
+        trapped = samples[:, 4] < 0.3
+        assert trapped.mean() <= 0.02 + 1e-9, (label, trapped.mean())  # at most two walkers of the hundred
+        bulk = samples[~trapped]
+        for d in range(6):
+            assert abs(bulk[:, d].mean() - ref_mean[d]) < 0.1 * ref_std[d], (label, d)
+            assert bulk[:, d].std() == pytest.approx(ref_std[d], rel=0.08), (label, d)
+
     np.random.seed(26)
     p0 = mcmc_utils.flat_seed(ps, nwalkers=100)
     samples = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500)   # LnProb -> device-resident
@@ -351,14 +380,22 @@ def test_mcmc_driver_device_resident(golden, capsys):
     acc = float(out.split("sum of acceptance fraction")[1].split()[0]) / 100
     assert 0.36 < acc < 0.50                                   # reference notebook: 0.427
     assert f.ncalls == 0                                       # no host-driven evaluations at all
-    # same posterior as the host-driven sampler
+    check(samples, "device-resident")
+    # the host-driven sampler (one launch + PCIe round trip per half-ensemble) on the same posterior
     np.random.seed(26)
     host = mcmc_utils.mcmc(p0=p0, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500, device_resident=False)
     capsys.readouterr()
-    for d in range(6):
-        sd = host[:, d].std()
-        assert abs(samples[:, d].mean() - host[:, d].mean()) < 0.25 * sd
-        assert samples[:, d].std() == pytest.approx(sd, rel=0.2)
+    assert f.ncalls > 0
+    check(host, "host-driven")
+    # a trapped walker is recognised as such: put one into the corner mode by hand and the bulk comparison still holds
+    p1 = p0.copy()
+    p1[0] = [0.35, 0.957, 0.74, 2.76, 0.0006, -0.81]           # a walker of the profile file's census (lnprob -385.6)
+    np.random.seed(27)
+    dev2 = mcmc_utils.mcmc(p0=p1, ln_prob=f, ndim=6, nwalkers=100, burnin=400, nsteps=1500)
+    capsys.readouterr()
+    assert (dev2[:, 4] < 0.3).mean() == pytest.approx(0.01, abs=1e-9)   # that walker stays where it is ...
+    assert dev2[:, 4].std() > 1.5 * ref_std[4]                 # ... and inflates the naive width as in the recorded failure
+    check(dev2, "device-resident, one walker trapped")
     f.close()
 
 
