@@ -110,9 +110,16 @@ static __device__ GF_MIX_ATTR void mixing_cols12(double s12_2, double c13_4, dou
 // of non-negative terms for positive semi-definite S', N') and cost ~40 fewer fp64 instructions per bin.
 struct BinInv {
     double trS, trN;
+    double tau;                 // trN / trS: a bin's SM weight is a = 1 / (1 + rho_k tau)
     double bS, bSN, bN, m1, m2;
     double sd0, sd1, nd0, nd1;
     double qS0, qX0, qN0, qS1, qX1, qN1;
+    // the same quadratics in the one variable a (t = 1 - a), Horner form x0 + a (x1 + a x2), for the value loop: b, the two
+    // off-diagonal sums and (linear) the two diagonal entries.  Absolute accuracy relative to the unit trace is all the
+    // eigenvector-eigenvalue identity asks of them (gf_bsm.hip, numerics note); det keeps its factored form a t (a m1 + t m2).
+    double b1, b2;              // b  = bN  + a (b1 + a b2)
+    double o01, o02, o11, o12;  // os = qN + a (o.1 + a o.2)
+    double e0, e1;              // d  = nd + a e.
 };
 
 __device__ __forceinline__ Herm3 scaled(const Herm3& x, double s)
@@ -153,7 +160,9 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 {
     w.trS = (S.d0 + S.d1) + S.d2;
     w.trN = (N.d0 + N.d1) + N.d2;
-    Sn = scaled(S, fast_rcp(w.trS));
+    const double itS = fast_rcp(w.trS);
+    w.tau = w.trN * itS;
+    Sn = scaled(S, itS);
     Nn = scaled(N, fast_rcp(w.trN));
     w.bS = minor_sum(Sn);
     w.bN = minor_sum(Nn);
@@ -170,6 +179,10 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
     w.qS0 = s01 + s02; w.qS1 = s01 + s12;
     w.qN0 = n01 + n02; w.qN1 = n01 + n12;
     w.qX0 = 2.0 * (x01 + x02); w.qX1 = 2.0 * (x01 + x12);
+    w.b1 = fma(-2.0, w.bN, w.bSN);  w.b2 = (w.bS - w.bSN) + w.bN;
+    w.o01 = fma(-2.0, w.qN0, w.qX0); w.o02 = (w.qS0 - w.qX0) + w.qN0;
+    w.o11 = fma(-2.0, w.qN1, w.qX1); w.o12 = (w.qS1 - w.qX1) + w.qN1;
+    w.e0 = w.sd0 - w.nd0; w.e1 = w.sd1 - w.nd1;
 }
 
 // One energy bin: eigenvalues of the trace-normalised H by the trigonometric cubic solution
@@ -177,16 +190,25 @@ __device__ __forceinline__ void bin_invariants(const Herm3& S, const Herm3& N, H
 // (alpha, i) in {e, mu} x {0, 1}; the remaining five follow from the unit row and column sums of |U|^2.
 // Optionally the reference's eigenvector form for the unitarity status.
 template <int UNI_MODE>
-__device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double u, double v,
+// `rho` = E^(d-3) / (1 / 2E) of the bin (GfBsm::rho).  Output: the 2x2 block p[0..1][0..1] only; the other five entries follow
+// from the unit row and column sums where the caller needs them.
+__device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, const Herm3& Nn, double rho,
                                            double p[3][3], UniAcc& acc, int kbin, const GfBsm* __restrict__ tb)
 {
     constexpr bool CHECK_UNI = UNI_MODE == UNI_ONLY;                 // the values and the estimate never share a loop body
-    const double al = u * w.trS, be = v * w.trN;
-    const double s = fast_rcp(al + be);
-    const double a = al * s, t = be * s;
+    // H / tr H = a S' + t N' with a = u trS / (u trS + v trN) = 1 / (1 + rho tau), t = 1 - a = rho tau a: both to full relative
+    // accuracy at either end (a -> 1e-20 at the top of a scale range, t -> 1e-20 at its bottom)
+    const double rt = rho * w.tau;
+    const double a = fast_rcp(rt + 1.0), t = rt * a;
     if (UNI_MODE == UNI_ONLY && !(a < tb->uni_a_ok)) return;          // tier 1 clears this bin: nothing to evaluate
-    const double aa = a * a, at = a * t, tt = t * t;
-    const double b = fma(aa, w.bS, fma(at, w.bSN, tt * w.bN));
+    const double at = a * t;
+    double b;
+    if (CHECK_UNI) {                                                  // the estimate keeps the arithmetic its bands were calibrated on
+        const double aa = a * a, tt = t * t;
+        b = fma(aa, w.bS, fma(at, w.bSN, tt * w.bN));
+    } else {
+        b = fma(a, fma(a, w.b2, w.b1), w.bN);
+    }
     const double det = at * fma(a, w.m1, t * w.m2);
     const double Q = fma(-3.0, b, 1.0) * (1.0 / 9.0);                 // (a^2 - 3b)/9 with a = -tr = -1
     const double R = (fma(9.0, b, -2.0) - 27.0 * det) * (1.0 / 54.0); // (2a^3 - 9ab + 27c)/54, c = -det
@@ -209,34 +231,38 @@ __device__ __forceinline__ void bin_moduli(const BinInv& w, const Herm3& Sn, con
     const double sq = fast_sqrt(Q);
     double x = R * fast_rcp(Q * sq);
 #endif
-    x = fmin(1.0, fmax(-1.0, x));
-    const double phi = fast_acos(x) * (1.0 / 3.0);
+    // (rounding can leave |x| a hair above one: fast_acos_clamped takes that as one)
+    const double phi = fast_acos_clamped(x) * (1.0 / 3.0);
     double sp, cp;
     sincos_small(phi, &sp, &cp);
     const double m2 = -2.0 * sq;
     const double HS3 = 0.8660254037844386;                            // sqrt(3)/2
-    const double A = 1.5 * cp, B = HS3 * sp;
-    const double E0 = fma(m2, cp, 1.0 / 3.0);                         // fr.py:212
-    const double E1 = fma(m2, B - 0.5 * cp, 1.0 / 3.0);               // cos(phi - 2pi/3), fr.py:213
-    const double E2 = fma(m2, -B - 0.5 * cp, 1.0 / 3.0);              // cos(phi + 2pi/3), fr.py:214
-    // eigenvalue gaps in closed form (no cancellation near a level crossing):
-    // E0 - E1 = m2 (A - B), E0 - E2 = m2 (A + B), E1 - E2 = 2 m2 B
-    const double g01 = m2 * (A - B), g02 = m2 * (A + B), g12 = 2.0 * (m2 * B);
+    // E_k = m2 cos(phi + {0, -2pi/3, +2pi/3}) + 1/3 (fr.py:212-214) = mc + 1/3, -mc/2 +- mb + 1/3 with mc = m2 cos phi,
+    // mb = m2 (sqrt(3)/2) sin phi; the eigenvalue gaps in closed form (no cancellation near a level crossing):
+    // E0 - E1 = 3/2 mc - mb, E0 - E2 = 3/2 mc + mb, E1 - E2 = 2 mb
+    const double mc = m2 * cp, mb = m2 * (HS3 * sp);
+    const double E0 = mc + 1.0 / 3.0;
+    const double eb = fma(-0.5, mc, 1.0 / 3.0);
+    const double E1 = eb + mb, E2 = eb - mb;
+    const double g01 = fma(1.5, mc, -mb), g02 = fma(1.5, mc, mb), g12 = mb + mb;
     const double r = fast_rcp((g01 * g02) * g12);
     const double inv0 = g12 * r;                                      // 1 / ((E0 - E1)(E0 - E2))
     const double inv1 = -(g02 * r);                                   // 1 / ((E1 - E2)(E1 - E0))
-    const double d0 = fma(a, w.sd0, t * w.nd0), d1 = fma(a, w.sd1, t * w.nd1);
-    const double os0 = fma(aa, w.qS0, fma(at, w.qX0, tt * w.qN0));
-    const double os1 = fma(aa, w.qS1, fma(at, w.qX1, tt * w.qN1));
+    double d0, d1, os0, os1;
+    if (CHECK_UNI) {
+        const double aa = a * a, tt = t * t;
+        d0 = fma(a, w.sd0, t * w.nd0); d1 = fma(a, w.sd1, t * w.nd1);
+        os0 = fma(aa, w.qS0, fma(at, w.qX0, tt * w.qN0));
+        os1 = fma(aa, w.qS1, fma(at, w.qX1, tt * w.qN1));
+    } else {
+        d0 = fma(a, w.e0, w.nd0); d1 = fma(a, w.e1, w.nd1);
+        os0 = fma(a, fma(a, w.o02, w.o01), w.qN0);
+        os1 = fma(a, fma(a, w.o12, w.o11), w.qN1);
+    }
     p[0][0] = fma(d0 - E1, d0 - E2, os0) * inv0;
     p[0][1] = fma(d0 - E2, d0 - E0, os0) * inv1;
     p[1][0] = fma(d1 - E1, d1 - E2, os1) * inv0;
     p[1][1] = fma(d1 - E2, d1 - E0, os1) * inv1;
-    p[0][2] = (1.0 - p[0][0]) - p[0][1];
-    p[1][2] = (1.0 - p[1][0]) - p[1][1];
-    p[2][0] = (1.0 - p[0][0]) - p[1][0];
-    p[2][1] = (1.0 - p[0][1]) - p[1][1];
-    p[2][2] = (1.0 - p[0][2]) - p[1][2];
 
     if (CHECK_UNI && a < tb->uni_a_ok) {
         // fr.py:216-236 in fp64, then fr.py:489-494.  h10 = conj(h01) etc.
@@ -315,10 +341,10 @@ __device__ __forceinline__ void tier2_bins(const GfBsm* __restrict__ tb, const B
     const double skip_be = (1.0 - tb->uni_a_ok) * fast_rcp(tb->uni_a_ok) * (1.0 - 1e-9);
     const int nb = tb->nbins;
     for (int k = sub; k < nb; k += lpw) {
-        const double u = tb->inv2e[k], v = tb->epow[k];
-        if (v * w.trN < skip_be * (u * w.trS)) continue;
+        const double rho = tb->rho[k];
+        if (rho * w.tau < skip_be) continue;
         double p[3][3];
-        bin_moduli<UNI_ONLY>(w, Sn, Nn, u, v, p, acc, k, tb);
+        bin_moduli<UNI_ONLY>(w, Sn, Nn, rho, p, acc, k, tb);
     }
 }
 __device__ __forceinline__ void tier2_from_sn(const GfBsm* __restrict__ tb, const Herm3& S, const Herm3& N, UniAcc& acc)
@@ -395,25 +421,29 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     // source_flux[k] = source_ratio * E_k^gamma (fr.py:416-419) enters u_to_fr only through
     // src / sum(src) (fr.py:535): the E^gamma factor cancels, so the spectral index has no effect.
     const double isrc = fast_rcp(c.src_fixed_sum);
-    const double s0 = c.src_fixed[0] * isrc, s1 = c.src_fixed[1] * isrc, s2 = c.src_fixed[2] * isrc;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const double s2 = c.src_fixed[2] * isrc;
+    const double ds0 = fma(c.src_fixed[0], isrc, -s2), ds1 = fma(c.src_fixed[1], isrc, -s2);
+    // fr.py:451 u_to_fr: f = P P^T s with P = |U|^2, s = src / sum(src).  P's rows and columns sum to one, so only its 2x2 block
+    // is needed: w = P^T s = s2 + ds0 P_0. + ds1 P_1. (ds = s - s2), f_b = w2 + P_b0 (w0 - w2) + P_b1 (w1 - w2) for b = e, mu, and
+    // f_tau = (sum s) - f_e - f_mu -- which makes the tau row of the width-weighted sum (sum of the widths) - a0 - a1: 18
+    // instructions per bin where the full 3x3 products took 31.
+    double a0 = 0.0, a1 = 0.0;
     const int nb = tb->nbins;
     for (int k = (LPW > 1 ? sub : 0); k < nb; k += LPW) {
-        const double u = tb->inv2e[k], v = tb->epow[k];
         double p[3][3];
-        bin_moduli<UNI_MODE>(w, Sn, Nn, u, v, p, acc, k, tb);
-        // fr.py:451 u_to_fr: f = |U|^2 (|U|^2)^T src / sum(src)
-        const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
-        const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
-        const double w2 = fma(p[2][2], s2, fma(p[1][2], s1, p[0][2] * s0));
-        const double f0 = fma(p[0][2], w2, fma(p[0][1], w1, p[0][0] * w0));
-        const double f1 = fma(p[1][2], w2, fma(p[1][1], w1, p[1][0] * w0));
-        const double f2 = fma(p[2][2], w2, fma(p[2][1], w1, p[2][0] * w0));
+        bin_moduli<UNI_MODE>(w, Sn, Nn, tb->rho[k], p, acc, k, tb);
+        const double p02 = (1.0 - p[0][0]) - p[0][1], p12 = (1.0 - p[1][0]) - p[1][1];
+        const double w0 = fma(ds1, p[1][0], fma(ds0, p[0][0], s2));
+        const double w1 = fma(ds1, p[1][1], fma(ds0, p[0][1], s2));
+        const double w2 = fma(ds1, p12, fma(ds0, p02, s2));
+        const double dw0 = w0 - w2, dw1 = w1 - w2;
+        const double f0 = fma(p[0][1], dw1, fma(p[0][0], dw0, w2));
+        const double f1 = fma(p[1][1], dw1, fma(p[1][0], dw0, w2));
         if (LPW > 1) {
-            fgrp[3 * k] = f0; fgrp[3 * k + 1] = f1; fgrp[3 * k + 2] = f2;
+            fgrp[3 * k] = f0; fgrp[3 * k + 1] = f1;
         } else {
             const double wk = tb->weight[k];
-            a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1); a2 = fma(f2, wk, a2);   // fr.py:454
+            a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1);                         // fr.py:454
         }
     }
     // UNI_INLINE, second phase: tier 2 for the walkers tier 1 does not clear (none where the posterior lives).  The terms
@@ -443,7 +473,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int k = 0; k < nb; ++k) {
             const double wk = tb->weight[k];
-            a0 = fma(fgrp[3 * k], wk, a0); a1 = fma(fgrp[3 * k + 1], wk, a1); a2 = fma(fgrp[3 * k + 2], wk, a2);
+            a0 = fma(fgrp[3 * k], wk, a0); a1 = fma(fgrp[3 * k + 1], wk, a1);
         }
         if (UNI_MODE == UNI_INLINE) {
 #pragma unroll
@@ -454,6 +484,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
             }
         }
     }
+    const double a2 = (tb->wsum - a0) - a1;                         // the tau row: (sum of the widths) sum(s) - a0 - a1, sum(s) = 1
     const double inv = fast_rcp((a0 + a1) + a2);                    // fr.py:457
     fr[0] = a0 * inv; fr[1] = a1 * inv; fr[2] = a2 * inv;
 }

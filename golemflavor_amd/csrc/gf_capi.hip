@@ -663,6 +663,8 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
             b.epow[k] = std::pow(e, (double)(d->dimension - 3));                   // fr.py:394
             const double rho = b.epow[k] / b.inv2e[k];
             if (k == 0 || rho > b.rho_max) b.rho_max = rho;
+            b.rho[k] = rho;
+            b.wsum += b.weight[k];
         }
         if (d->texture != GF_TEX_NONE) {
             const double z = 0. + 1e-9;                                            // fr.py:370

@@ -69,6 +69,8 @@ struct GfBsm {
     double uni_lo, uni_hi;          // a >= uni_a_lin
     double uni_lo_nl;               // a <  uni_a_lin: the estimate acquits only far below the threshold and never condemns
     double rho_max;                 // max_k epow[k] / inv2e[k]: the smallest SM weight over the bins is 1 / (1 + rho_max trN / trS)
+    double rho[GF_MAX_BINS];        // epow[k] / inv2e[k]: the bin's SM weight is a = 1 / (1 + rho[k] trN / trS)
+    double wsum;                    // sum_k weight[k] (fp64, in index order)
 };
 
 // Work queue of the unitarity arbitration (gf_unitarity.hip): the WALKERS whose verdict the fp64 estimate of the reference's

@@ -197,6 +197,30 @@ __device__ __forceinline__ double fast_acos(double x)
     return x < 0.0 ? 3.141592653589793 - a : a;
 }
 
+// the same for an argument that rounding may have pushed a hair beyond [-1, 1] (the cubic's R / Q^(3/2)): taken as +-1.  One
+// max on z where a clamp of x costs a min and a max: |x| > 1 only shows up in the big branch, as a negative z.
+__device__ __forceinline__ double fast_acos_clamped(double x)
+{
+    const double* k = GF_KTAB + 16;
+    const double ax = fabs(x);
+    const bool big = ax > 0.5;
+    const double z = big ? fmax(fma(-0.5, ax, 0.5), 0.0) : x * x;
+    const double s = big ? fast_sqrt(z) : ax;
+    double p = fma(z, k[0], k[1]);
+    p = fma(z, p, k[2]);
+    p = fma(z, p, k[3]);
+    p = fma(z, p, k[4]);
+    p = fma(z, p, k[5]);
+    double q = fma(z, k[6], k[7]);
+    q = fma(z, q, k[8]);
+    q = fma(z, q, k[9]);
+    q = fma(z, q, 1.0);
+    const double r = (z * p) * fast_rcp(q);
+    const double as = fma(s, r, s);                                  // asin(s)
+    const double a = big ? as + as : 1.5707963267948966 - as;        // acos(|x|)
+    return x < 0.0 ? 3.141592653589793 - a : a;
+}
+
 // 10^x for the NP scale (fr.py:380 np.power(10., logLam)), once per walker.  The library pow(10, x) is ~200 instructions
 // behind a call; for |x| < 300 (every scale a paramset of the reference can hold: -72 ... -20) this is 22: n = rint(x log2 10),
 // r = x - n log10(2) by a two-constant Cody-Waite reduction (the high part has 33 bits: n * hi is exact), 10^r as the degree-14
