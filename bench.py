@@ -188,7 +188,8 @@ def extra_c3(device):
             "GBps_algorithmic": 24 * n / ms / 1e6, "frac_of_hbm_peak": 24 * n / ms / 1e6 / HBM_PEAK_GBS,
             "with_angles": {"kernel_ms": ms_a, "draws_per_s": n / ms_a * 1e3, "bytes_per_draw": 56,
                             "frac_of_hbm_peak": 56 * n / ms_a / 1e6 / HBM_PEAK_GBS},
-            "bound": "integer VALU (two Philox4x32-10 blocks per draw), not HBM"}
+            "bound": "VALU issue, not HBM: 176 VALU instructions per wave of draws, a third of the issue time in the 34 v_mad_u64_u32 of "
+                     "the two Philox4x32-10 blocks, whose stream is fixed (the oracle's, bit for bit); profiles/r03/haar.txt"}
 
 
 def extra_bulk(device, ps, label, n=4 * 1024 * 1024):

@@ -268,9 +268,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t m0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        // three-input exclusive or in ONE instruction (v_bitop3_b32, truth table 0x96; gfx950): the compiler emits two v_xor_b32
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(m1 >> 32), c1, k0, 0x96);
         const uint32_t n1 = (uint32_t)m1;
-        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(m0 >> 32), c3, k1, 0x96);
         const uint32_t n3 = (uint32_t)m0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -284,6 +285,31 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
     return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// Composition of one Haar draw: u_to_fr(source, angles_to_u(angles)) (scripts/mc_unitary.py:189-193) with only the 2 x 3
+// block of |U|^2 that the unit row and column sums leave independent -- w = P^T s = s2 + ds0 P_0. + ds1 P_1. (ds = s - s2),
+// f_b = w2 + P_b0 (w0 - w2) + P_b1 (w1 - w2) for b = e, mu, f_tau = sum(w) - f_e - f_mu: ~60 fp64 instructions where
+// pmns_abs2 + propagate take ~85 (the kernel is VALU-bound: the arithmetic around the two Philox blocks is a third of it).
+__device__ __forceinline__ void haar_composition(double s12_2, double c13_4, double s23_2, double dcp, double s2, double ds0, double ds1,
+                                                 double fr[3])
+{
+    const double c13_2 = fast_sqrt(c13_4);
+    const double s13_2 = 1.0 - c13_2;
+    const double c12_2 = 1.0 - s12_2;
+    const double c23_2 = 1.0 - s23_2;
+    const double a = s12_2 * c23_2, b = c12_2 * s23_2;
+    const double e = c12_2 * c23_2, f = s12_2 * s23_2;
+    const double j2 = 2.0 * fast_sqrt((a * b) * s13_2) * fast_cos_phase(dcp);
+    const double p00 = c12_2 * c13_2, p01 = s12_2 * c13_2, p02 = s13_2;
+    const double p10 = fma(b, s13_2, a) + j2, p11 = fma(f, s13_2, e) - j2, p12 = s23_2 * c13_2;
+    const double w0 = fma(ds1, p10, fma(ds0, p00, s2));
+    const double w1 = fma(ds1, p11, fma(ds0, p01, s2));
+    const double w2 = fma(ds1, p12, fma(ds0, p02, s2));
+    const double dw0 = w0 - w2, dw1 = w1 - w2;
+    fr[0] = fma(p01, dw1, fma(p00, dw0, w2));
+    fr[1] = fma(p11, dw1, fma(p10, dw0, w2));
+    fr[2] = (((w0 + w1) + w2) - fr[0]) - fr[1];
+}
+
 // Haar draws: angles ~ U([0,1]^3 x [0,2pi]) (the flat prior of scripts/mc_unitary.py:35-40), then
 // angles_to_u -> u_to_fr(source_ratio) (mc_unitary.py:189-193).  24 B written per draw.
 __global__ __launch_bounds__(GF_BLOCK) void k_haar(const GfCommon c, uint64_t seed, int64_t first, int64_t n,
@@ -291,6 +317,8 @@ __global__ __launch_bounds__(GF_BLOCK) void k_haar(const GfCommon c, uint64_t se
 {
     const int64_t stride = (int64_t)gridDim.x * GF_BLOCK;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const double isrc = fast_rcp(c.src_fixed_sum);
+    const double s2 = c.src_fixed[2] * isrc, ds0 = fma(c.src_fixed[0], isrc, -s2), ds1 = fma(c.src_fixed[1], isrc, -s2);
     for (int64_t i = (int64_t)blockIdx.x * GF_BLOCK + threadIdx.x; i < n; i += stride) {
         const uint64_t ctr = (uint64_t)(first + i);
         uint32_t a[4], b[4];
@@ -300,10 +328,8 @@ __global__ __launch_bounds__(GF_BLOCK) void k_haar(const GfCommon c, uint64_t se
         const double c13_4 = u53(a[2], a[3]);
         const double s23_2 = u53(b[0], b[1]);
         const double dcp = 6.283185307179586 * u53(b[2], b[3]);
-        double p[3][3], fr[3];
-        pmns_abs2(s12_2, c13_4, s23_2, dcp, p);
-        const double src[3] = {c.src_fixed[0], c.src_fixed[1], c.src_fixed[2]};
-        propagate(p, src, c.src_fixed_sum, fr);
+        double fr[3];
+        haar_composition(s12_2, c13_4, s23_2, dcp, s2, ds0, ds1, fr);
         fr_out[3 * i] = fr[0]; fr_out[3 * i + 1] = fr[1]; fr_out[3 * i + 2] = fr[2];
         if (angles) {
             double4 v; v.x = s12_2; v.y = c13_4; v.z = s23_2; v.w = dcp;

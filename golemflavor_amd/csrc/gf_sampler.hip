@@ -41,9 +41,9 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
     for (int r = 0; r < 10; ++r) {
         const uint64_t m0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(m1 >> 32), c1, k0, 0x96);     // xor of three, one instruction
         const uint32_t n1 = (uint32_t)m1;
-        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(m0 >> 32), c3, k1, 0x96);
         const uint32_t n3 = (uint32_t)m0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
