@@ -342,9 +342,8 @@ __device__ __forceinline__ void pmns_abs2(double s12_2, double c13_4, double s23
     p[1][0] = fma(b, s13_2, a) + j2;
     p[1][1] = fma(f, s13_2, e) - j2;
     p[1][2] = s23_2 * c13_2;
-    p[2][0] = fma(e, s13_2, f) - j2;
-    p[2][1] = fma(a, s13_2, b) + j2;
-    p[2][2] = c23_2 * c13_2;
+    // (the tau row |Ut1|^2 = e s13^2 + f - 2 J cos d, |Ut2|^2 = a s13^2 + b + 2 J cos d, |Ut3|^2 = c23^2 c13^2 is not formed: the
+    // columns of |U|^2 sum to one and `propagate` uses that)
 }
 
 // golemflavor/fr.py:82-113 angles_to_fr: (sin^4 phi, cos 2psi) -> composition.  sin^2(acos(c)/2) =
@@ -359,19 +358,25 @@ __device__ __forceinline__ void angles_to_fr(double sphi4, double c2psi, double 
     f[2] = fabs(1.0 - sphi2);
 }
 
-// golemflavor/fr.py:502-536 u_to_fr: out_b = sum_a sum_i |U_ai|^2 |U_bi|^2 src_a / sum(src).
-// Evaluated as two 3x3 matrix-vector products, w_i = sum_a |U_ai|^2 src_a / sum(src) and
-// out_b = sum_i |U_bi|^2 w_i (18 FMAs), instead of forming P = |U|^2 |U|^2^T (27).
+// golemflavor/fr.py:502-536 u_to_fr: out_b = sum_a sum_i |U_ai|^2 |U_bi|^2 src_a / sum(src) = (P P^T s)_b with P = |U|^2 and
+// s = src / sum(src).  The rows and columns of P sum to one, so its e and mu rows carry everything:
+//   w = P^T s = s_tau + (s_e - s_tau) P_e. + (s_mu - s_tau) P_mu.          (6 FMAs)
+//   out_b = w_3 + P_b1 (w_1 - w_3) + P_b2 (w_2 - w_3),  b = e, mu         (2 + 4)
+//   out_tau = (w_1 + w_2 + w_3) - out_e - out_mu                           (4)
+// 16 instructions behind the normalisation where the two full 3x3 matrix-vector products took 18 plus the tau row of P (5).
+// `p`: rows 0 and 1 only are read.
 __device__ __forceinline__ void propagate(const double p[3][3], const double src[3], double src_sum, double out[3])
 {
     const double inv = fast_rcp(src_sum);
-    const double s0 = src[0] * inv, s1 = src[1] * inv, s2 = src[2] * inv;
-    const double w0 = fma(p[2][0], s2, fma(p[1][0], s1, p[0][0] * s0));
-    const double w1 = fma(p[2][1], s2, fma(p[1][1], s1, p[0][1] * s0));
-    const double w2 = fma(p[2][2], s2, fma(p[1][2], s1, p[0][2] * s0));
-    out[0] = fma(p[0][2], w2, fma(p[0][1], w1, p[0][0] * w0));
-    out[1] = fma(p[1][2], w2, fma(p[1][1], w1, p[1][0] * w0));
-    out[2] = fma(p[2][2], w2, fma(p[2][1], w1, p[2][0] * w0));
+    const double s2 = src[2] * inv;
+    const double ds0 = fma(src[0], inv, -s2), ds1 = fma(src[1], inv, -s2);
+    const double w0 = fma(ds1, p[1][0], fma(ds0, p[0][0], s2));
+    const double w1 = fma(ds1, p[1][1], fma(ds0, p[0][1], s2));
+    const double w2 = fma(ds1, p[1][2], fma(ds0, p[0][2], s2));
+    const double dw0 = w0 - w2, dw1 = w1 - w2;
+    out[0] = fma(p[0][1], dw1, fma(p[0][0], dw0, w2));
+    out[1] = fma(p[1][1], dw1, fma(p[1][0], dw0, w2));
+    out[2] = (((w0 + w1) + w2) - out[0]) - out[1];
 }
 
 // golemflavor/llh.py:32-54 multi_gaussian = log(mvn.pdf) + offset.  scipy evaluates

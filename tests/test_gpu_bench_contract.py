@@ -35,3 +35,32 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
     assert d["parity_max_rel_vs_oracle"] < 1e-10
+
+
+@pytest.mark.gpu
+def test_bench_line_sub_records_at_reduced_scan_length():
+    """The sub-records of the line through the real command, the sharded scans at a reduced chain length (the full
+    reference length is exercised by tests/test_gpu_mcmc.py::test_reference_length_scan_on_one_gpu): every BASELINE
+    configuration is present, none carries an `error`, and the scan records have the per-phase keys of the N-rank line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-sample", "20000",
+           "--scan-burnin", "20", "--scan-nsteps", "40"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("c3", "c4_bulk", "c5_bulk", "c4_scan", "c5_scan", "c4_scan_ref", "c5_scan_ref", "emcee_driven", "emcee_driven_c1_scaling",
+                "cpu_baseline", "roofline"):
+        assert key in d and "error" not in d[key], (key, d.get(key))
+    assert d["diagnostic_overrides"] == ""
+    for key, npts, nw in (("c4_scan_ref", 64, 2048), ("c5_scan_ref", 256, 512)):
+        s = d[key]
+        assert s["ranks"] == 1 and s["grid_points"] == npts and s["walkers"] == nw and s["burnin"] == 20 and s["nsteps"] == 40
+        assert s["scaling"].startswith("strong")
+        for k in ("seconds", "evals_per_s", "setup_s", "sampling_s", "pack_s", "xgmi_s", "gather_bytes", "d2h_s", "gather", "phases"):
+            assert k in s, (key, k)
+        assert s["evals_per_s"] == pytest.approx(s["evals"] / s["seconds"])
+        assert s["finite_fraction"] > 0.9
+    assert d["c5_scan_ref"]["nonunitary_proposals"]["settled"].startswith("on the device")
+    fr = d["c4_bulk"]["with_status_through_the_failing_region"]
+    assert fr["evals_per_s"] > 3e8 and 0.1 < fr["nonunitary_fraction"] < 0.3          # round 2: 1.5e8

@@ -171,6 +171,50 @@ def test_reference_length_scan_on_one_gpu(config):
     assert rec["evals_per_s"] > 1e8
 
 
+_TWO_RANK_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from golemflavor_amd import scan
+out = sys.argv[2]
+scan.main(["--config", sys.argv[3], "--points", "5", "--nwalkers", "32", "--burnin", "6", "--nsteps", "9"] +
+          (["--outfile", out] if int(os.environ["RANK"]) == 0 else []))
+"""
+
+
+@pytest.mark.parametrize("config", ["C4", "C5"])
+def test_scan_gathers_over_rccl_between_two_gpus(config, tmp_path, capsys):
+    """The N > 1 data path on hardware: two ranks on two DISTINCT devices, descriptors and the RCCL id over the socket control
+    plane, chains gathered to rank 0 with gf_comm_gather over xGMI (5 grid points on 2 ranks: ragged), one download.  The
+    result must be the single-rank scan's, bit for bit.  Skipped on a one-GPU box -- where RCCL with more than one rank has
+    never run (multi-GPU unmeasured)."""
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import socket
+    import subprocess
+    import sys
+    from golemflavor_amd import scan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scan.main(["--config", config, "--points", "5", "--nwalkers", "32", "--burnin", "6", "--nsteps", "9", "--outfile", str(tmp_path / "one")])
+    capsys.readouterr()
+    script = tmp_path / "child.py"
+    script.write_text(_TWO_RANK_CHILD)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "two"), config], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["ranks"] == 2 and line["gather"] == "rccl device gather to rank 0" and line["rccl_error"] is None
+    a, b = np.load(str(tmp_path / "one.npy")), np.load(str(tmp_path / "two.npy"))
+    assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
 def test_scan_rows_to_host_equal_rows_on_device():
     """gf_sampler_postprocess_rows hands the scan's rows to the host group by group while later chains are still being
     post-processed; they must be the rows gf_sampler_postprocess_rows_device assembles (19 chains: ragged last group)."""
