@@ -637,10 +637,15 @@ hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t 
 {
     constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
     const int64_t nprop = (int64_t)a.nchains * (a.nwalkers / 2);
-    // enough groups to spread a short queue's walkers over (fan-out); on an empty queue every block returns after one load
+    // enough groups to spread a short queue's walkers over (fan-out); on an empty queue every block returns after one load.  One
+    // block per CU: measured on the C5 scan's sampling phase (256 chains x 512 walkers, a few hundred parked proposals per
+    // half-step) 128 / 256 / 512 / 1024 / 2048 blocks give 0.105 / 0.120 / 0.116 / 0.130 / 0.141 s -- the step waits for ONE walker's
+    // chain of dependent instructions (~70 us for the set-up and one bin, tools/arb_latency_probe.py), not for throughput
     int64_t blocks = (nprop * GF_UNI_MAX_FANOUT + per_block - 1) / per_block;
-    if (blocks > 2 * cus) blocks = 2 * cus;
+    if (blocks > cus) blocks = cus;
     if (blocks < 1) blocks = 1;
+    static const int forced = [] { const char* e = gf_internal_env("GF_SETTLE_BLOCKS", 0); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
+    if (forced > 0) blocks = forced;
     hipLaunchKernelGGL(k_stretch_settle, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, a);
     return hipGetLastError();
 }
