@@ -1080,41 +1080,112 @@ int gf_memcpy_h2d(gf_model* m, void* dst_dev, const void* src_host, size_t bytes
     return GF_OK;
 }
 
+// ---- large device-to-host copies: a ring of pinned slots + host threads ----------------------------------------------------
+// hipMemcpy into pageable memory is at the mercy of the runtime's own choice between pinning the destination in place and
+// staging: measured on one box, in one process, five 1.9 GB read-backs into fresh arrays ran at 42, 52, 10, 51 and 15 GB/s
+// (tools/numa_probe.py; not a NUMA effect: the same with the threads bound to either node).  So reads of 16 MB and more bring
+// their own staging: eight pinned 16 MB slots per device (allocated once), the DMA engine fills slot c while host threads copy
+// slot c - 1 (and c - 2 ...) into the destination -- which also touches the destination's pages for the first time, from several
+// threads, so no separate page-mapping pass is needed.  PCIe runs at its pinned-memory rate whatever the destination is.
+namespace {
+constexpr size_t D2H_SLOT = (size_t)16 << 20;
+constexpr int D2H_SLOTS = 8;
+constexpr size_t D2H_RING_MIN = (size_t)16 << 20;
+struct D2HRing {
+    std::mutex mu;                                   // one large read-back at a time per device
+    void* slot[D2H_SLOTS] = {};
+    hipEvent_t ev[D2H_SLOTS] = {};
+};
+D2HRing g_d2h[POOL_MAX_DEVICES];
+
+void parallel_memcpy(char* dst, const char* src, size_t len)
+{
+    static const size_t nt_max = []() -> size_t {
+        if (const char* v = gf_internal_env("GF_D2H_THREADS", 0)) { const long k = std::atol(v); if (k >= 1 && k <= 64) return (size_t)k; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return hw >= 32 ? 8 : (hw >= 8 ? 4 : 1);
+    }();
+    size_t nt = nt_max;
+    const size_t min_per_thread = (size_t)2 << 20;
+    if (len / min_per_thread < nt) nt = len / min_per_thread ? len / min_per_thread : 1;
+    if (nt == 1) { std::memcpy(dst, src, len); return; }
+    const size_t per = ((len / nt) + 4095) / 4096 * 4096;
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nt; ++k) {
+        const size_t lo = k * per, hi = (k + 1 == nt || (k + 1) * per > len) ? len : (k + 1) * per;
+        if (lo >= len) break;
+        th.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, per < len ? per : len);
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
+// internal (also gf_sampler.hip): synchronous copy of `bytes` from device memory to any host memory, through the ring,
+// in order on `stream`.  `gate` (may be NULL): called before a chunk is issued with the end offset of that chunk; returns
+// once the source bytes [0, upto) are final (gf_sampler_postprocess_rows: the event of the group of chains they belong to),
+// non-zero to abandon the copy -- so ONE pipeline runs over a source that is still being produced.
+int gf_internal_d2h_gated(int device, void* stream, void* dst_host, const void* src_dev, size_t bytes,
+                          int (*gate)(void* ctx, size_t upto), void* gate_ctx)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool ring_off = gf_internal_env("GF_NO_D2H_PIPELINE", 0) != nullptr;            // diagnostics / A-B
+    if (bytes < D2H_RING_MIN || ring_off) {
+        if (gate && gate(gate_ctx, bytes) != 0) return GF_ERR_HIP;
+        GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        GF_HIP(hipStreamSynchronize(st));
+        return GF_OK;
+    }
+    D2HRing& R = g_d2h[device];
+    std::lock_guard<std::mutex> lk(R.mu);
+    for (int k = 0; k < D2H_SLOTS; ++k) {
+        if (!R.slot[k]) GF_HIP(hipHostMalloc(&R.slot[k], D2H_SLOT, hipHostMallocDefault));
+        if (!R.ev[k]) GF_HIP(hipEventCreateWithFlags(&R.ev[k], hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + D2H_SLOT - 1) / D2H_SLOT;
+    std::atomic<size_t> issued{0}, drained{0};
+    std::atomic<int> failed{0};
+    char* dst = static_cast<char*>(dst_host);
+    std::thread consumer([&]() {
+        for (size_t c = 0; c < nchunks; ++c) {
+            while (issued.load(std::memory_order_acquire) <= c && !failed.load()) std::this_thread::yield();
+            if (failed.load()) return;
+            if (hipEventSynchronize(R.ev[c % D2H_SLOTS]) != hipSuccess) { failed.store(1); return; }
+            const size_t off = c * D2H_SLOT, len = bytes - off < D2H_SLOT ? bytes - off : D2H_SLOT;
+            parallel_memcpy(dst + off, static_cast<const char*>(R.slot[c % D2H_SLOTS]), len);
+            drained.store(c + 1, std::memory_order_release);
+        }
+    });
+    hipError_t e = hipSuccess;
+    for (size_t c = 0; c < nchunks && e == hipSuccess && !failed.load(); ++c) {
+        while (c >= drained.load(std::memory_order_acquire) + D2H_SLOTS && !failed.load()) std::this_thread::yield();   // the slot is free
+        const size_t off = c * D2H_SLOT, len = bytes - off < D2H_SLOT ? bytes - off : D2H_SLOT;
+        if (gate && gate(gate_ctx, off + len) != 0) { failed.store(2); break; }
+        e = hipMemcpyAsync(R.slot[c % D2H_SLOTS], static_cast<const char*>(src_dev) + off, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(R.ev[c % D2H_SLOTS], st);
+        if (e == hipSuccess) issued.store(c + 1, std::memory_order_release);
+    }
+    if (e != hipSuccess) failed.store(1);
+    consumer.join();
+    if (e != hipSuccess) return hip_fail(e, "gf_internal_d2h");
+    if (failed.load()) {
+        std::snprintf(g_err, sizeof(g_err), failed.load() == 2 ? "gf_internal_d2h: the source was not completed" : "gf_internal_d2h: event wait failed");
+        return GF_ERR_HIP;
+    }
+    return GF_OK;
+}
+int gf_internal_d2h(int device, void* stream, void* dst_host, const void* src_dev, size_t bytes)
+{
+    return gf_internal_d2h_gated(device, stream, dst_host, src_dev, bytes, nullptr, nullptr);
+}
+
 int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (!m || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
     GF_HIP(hipSetDevice(m->device));
     GF_STREAM(m);
-    // A large read-back (the chains of a scan: gigabytes into a fresh array): a copy into pages that are not mapped yet runs
-    // at page-fault speed (11-20 GB/s against 48-56, tools/pcie_probe.hip), and mapping them first (gf_host_prepare) costs
-    // 8 ms per GiB -- so a helper thread maps chunk k + 1 while chunk k crosses PCIe.  (One byte per page is written ahead of
-    // the copy that overwrites the page anyway.)
-    constexpr size_t D2H_PIPE_MIN = (size_t)256 << 20, D2H_CHUNK = (size_t)128 << 20;
-    static const bool pipe_off = gf_internal_env("GF_NO_D2H_PIPELINE", 0) != nullptr;            // diagnostics / A-B
-    if (bytes < D2H_PIPE_MIN || pipe_off) {
-        GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
-        GF_HIP(hipStreamSynchronize(m->stream));
-        return GF_OK;
-    }
-    std::atomic<size_t> mapped{0};
-    char* dst = static_cast<char*>(dst_host);
-    std::thread mapper([&]() {
-        for (size_t off = 0; off < bytes; off += D2H_CHUNK) {
-            const size_t len = bytes - off < D2H_CHUNK ? bytes - off : D2H_CHUNK;
-            (void)gf_host_prepare(dst + off, len);
-            mapped.store(off + len, std::memory_order_release);
-        }
-    });
-    hipError_t e = hipSuccess;
-    for (size_t off = 0; off < bytes && e == hipSuccess; off += D2H_CHUNK) {
-        const size_t len = bytes - off < D2H_CHUNK ? bytes - off : D2H_CHUNK;
-        while (mapped.load(std::memory_order_acquire) < off + len) std::this_thread::yield();
-        e = hipMemcpyAsync(dst + off, static_cast<const char*>(src_dev) + off, len, hipMemcpyDeviceToHost, m->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
-    }
-    mapper.join();
-    if (e != hipSuccess) return hip_fail(e, "gf_memcpy_d2h");
-    return GF_OK;
+    return gf_internal_d2h(m->device, (void*)m->stream, dst_host, src_dev, bytes);
 }
 
 int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n, double* d_lnprob, double* d_fr,

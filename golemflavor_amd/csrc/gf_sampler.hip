@@ -551,6 +551,8 @@ void gf_internal_return_stream(int device, void* stream);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
                           int32_t* d_status);
 int gf_internal_check_overflow(int device, void* stream);
+int gf_internal_d2h_gated(int device, void* stream, void* dst_host, const void* src_dev, size_t bytes,
+                          int (*gate)(void* ctx, size_t upto), void* gate_ctx);
 }
 
 namespace {
@@ -1118,9 +1120,9 @@ int gf_sampler_postprocess_rows_device(gf_sampler* s, gf_model* const* models, d
 }
 
 // The scan's rows straight to the host.  The chains are post-processed in turn on the sampler's stream (everything is enqueued
-// at once); an event marks the end of every group of chains, and the host walks the groups: wait for the event, map the
-// destination pages of the group, copy it on a SECOND stream -- so the copies of finished groups overlap the evaluation (and
-// the x87 arbitration, which dominates a texture scan) of the later ones.
+// at once); an event marks the end of every group of chains, and one pinned-ring copy on a SECOND stream follows the events
+// chunk by chunk -- so the read-back of finished groups overlaps the evaluation (and the x87 arbitration, which dominates a
+// texture scan's post-processing) of the later ones.
 int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* rows)
 {
     if (!s || !rows) return GF_ERR_INVALID_ARG;
@@ -1164,27 +1166,20 @@ int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* 
                 e = hipEventRecord(ev[ch / per_group], st);
         }
         gf_internal_full_arbitration_grids(device0, stream, 0);
-        // the destination pages of group g + 1 are mapped while group g crosses PCIe (mapping costs 8 ms per GiB, the copy 18:
-        // one after the other they were a third of a texture scan's read-back)
-        auto span = [&](int g, size_t* off, size_t* len) {
-            const int ch0 = g * per_group, ch1 = ch0 + per_group < s->nchains ? ch0 + per_group : s->nchains;
-            *off = chain_bytes * (size_t)ch0; *len = chain_bytes * (size_t)(ch1 - ch0);
-        };
-        size_t off = 0, len = 0;
-        span(0, &off, &len);
-        (void)gf_host_prepare(reinterpret_cast<char*>(rows) + off, len);               // while the group is still being evaluated
-        for (int g = 0; g < ngroups && rc == GF_OK && e == hipSuccess; ++g) {
-            span(g, &off, &len);
-            e = hipEventSynchronize(ev[g]);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(reinterpret_cast<char*>(rows) + off, reinterpret_cast<const char*>(d_rows) + off, len,
-                                   hipMemcpyDeviceToHost, (hipStream_t)copy_stream);
-            if (g + 1 < ngroups) {
-                size_t off1 = 0, len1 = 0;
-                span(g + 1, &off1, &len1);
-                (void)gf_host_prepare(reinterpret_cast<char*>(rows) + off1, len1);
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)copy_stream);
+        // the rows cross PCIe on the copy stream through the library's pinned ring (gf_internal_d2h_gated: the DMA fills a slot
+        // while host threads empty the previous ones into `rows`, mapping its pages as they go) -- ONE pipeline over the whole
+        // block, each 16 MB chunk issued as soon as the group of chains it ends in has been post-processed on the sampler's stream
+        if (rc == GF_OK && e == hipSuccess) {
+            struct Gate { hipEvent_t* ev; size_t group_bytes; int ngroups, passed; } gt = {ev, chain_bytes * (size_t)per_group, ngroups, 0};
+            auto gate = [](void* ctx, size_t upto) -> int {
+                Gate* g = static_cast<Gate*>(ctx);
+                int need = (int)((upto + g->group_bytes - 1) / g->group_bytes);
+                if (need > g->ngroups) need = g->ngroups;
+                for (; g->passed < need; ++g->passed)
+                    if (hipEventSynchronize(g->ev[g->passed]) != hipSuccess) return 1;
+                return 0;
+            };
+            rc = gf_internal_d2h_gated(device0, copy_stream, rows, d_rows, chain_bytes * (size_t)s->nchains, gate, &gt);
         }
     }
     const hipError_t e2 = hipStreamSynchronize(st);

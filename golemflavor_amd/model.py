@@ -12,7 +12,7 @@ from ._lib import GF_LAYOUT_AOS, GF_LAYOUT_SOA, check  # noqa: F401
 
 
 PREPARE_MIN_BYTES = 32 << 20
-PREPARE_MAX_BYTES = 256 << 20      # from here on gf_memcpy_d2h maps the pages itself, chunk by chunk, overlapped with the copy
+PREPARE_MAX_BYTES = 16 << 20       # from here on gf_memcpy_d2h brings its own pinned staging; its host threads map the pages as they fill them
 
 
 def empty_for_download(shape, dtype=np.float64, copier_maps_pages=False):

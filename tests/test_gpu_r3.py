@@ -144,3 +144,20 @@ def test_device_trim_releases_idle_workspaces():
         got = m.lnprob(th)
     assert np.array_equal(want[0], got[0], equal_nan=True) and np.array_equal(want[1], got[1])
     assert _lib.lib().gf_device_trim(99, None) == _lib.GF_ERR_NO_DEVICE
+
+
+def test_large_reads_come_back_through_the_pinned_ring_intact():
+    """Device-to-host copies of 16 MB and more go through four pinned 32 MB slots and host threads (gf_internal_d2h); smaller
+    ones are a plain hipMemcpy.  Sizes either side of the threshold, not multiples of a slot or of a page, come back bit for
+    bit, also into a destination that is not page-aligned."""
+    rng = np.random.default_rng(11)
+    with Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY")) as m:
+        for nbytes in (8 * 1000, (16 << 20) - 8, (16 << 20) + 8, (32 << 20) + 8, 5 * (32 << 20) + 8 * 12345):
+            src = rng.integers(0, 2 ** 63, nbytes // 8, dtype=np.int64).view(np.float64)
+            d = m.alloc(nbytes).upload(src)
+            got = d.download((nbytes // 8,))
+            assert np.array_equal(got.view(np.int64), src.view(np.int64)), nbytes
+            back = np.empty(nbytes // 8 + 3)
+            _lib.check(_lib.lib().gf_memcpy_d2h(m._h, back[3:].ctypes.data, d.ptr, nbytes), "d2h")
+            assert np.array_equal(back[3:].view(np.int64), src.view(np.int64)), nbytes
+            d.free()
