@@ -190,7 +190,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_BSM_WAVES(UNI_MODE, NDIM)) void k_bsm(
                     if (!(acc.clear_max < tb->uni_hi)) st = ST_NON_UNITARY;
                     // undecided bins: the x87-faithful evaluation settles them (gf_unitarity.hip); until then the
                     // walker counts as unitary
-                    else if (inbox && acc.amb != 0 && sub == 0 && uq) queue_walker(uq, i, acc.amb);
+                    else if (inbox && acc.amb != 0 && sub == 0 && uq) queue_walker(uq, i, uni_arbitration_mask(acc.amb, tb));
                 }
                 if (UNI_MODE == UNI_DEFER) defer = inbox && acc.a_min < tb->uni_a_ok;      // tier 1 does not clear this walker
                 if (WITH_LLH) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_T2_WAVES) void k_bsm_tier2(const GfBsm
             status[i] = ST_NON_UNITARY;
             if (lnprob) lnprob[i] = gf_nan();
         } else if (acc.amb != 0) {
-            queue_walker(uq, i, acc.amb);
+            queue_walker(uq, i, uni_arbitration_mask(acc.amb, tb));
         }
     }
     // the walker queue is re-armed by k_uni_resolve, which follows in stream order (one store there instead of a fence

@@ -37,6 +37,23 @@ struct UniAcc {
     double a_min;               // smallest SM weight over the bins (UNI_DEFER: what tier 1 needs, the rest runs later)
 };
 
+// What goes to the x87 arbitration for a walker with undecided bins: those bins AND every bin above the lowest of them.
+// The amplification of the rounding noise grows with the energy (the SM weight a falls from bin to bin), so a bin that
+// tier 2 would acquit on its own estimate while a LOWER bin is undecided owes that to an unusually quiet fp64 evaluation
+// (or the chain's residual to an unusually loud x87 one): over 2.4 M walkers of eight (dimension, texture) cases the 21
+// walkers whose status differed from the verdict of the chain run on every bin all had exactly that shape -- one failing
+// bin, residual 1.03e-7 ... 1.42e-7, next to undecided ones (profiles/r03/tier2_pairs.txt).  The arbitration takes a
+// walker's bins from the top down and stops at the first failure, so a failing walker costs nothing more; a unitary one
+// has its top bins undecided anyway.  (The bins tier 1 clears have the largest a: they lie below the lowest undecided bin.)
+__device__ __forceinline__ unsigned long long uni_arbitration_mask(unsigned long long amb, const GfBsm* __restrict__ tb)
+{
+    const int nbins = tb->nbins;
+    if (amb == 0ull || tb->uni_own_bins_only) return amb;
+    const unsigned long long lowest = amb & (~amb + 1ull);
+    const unsigned long long all = nbins >= 64 ? ~0ull : (1ull << nbins) - 1ull;
+    return all & ~(lowest - 1ull);
+}
+
 // How much of the unitarity verdict a call of flux_average / bin_moduli carries besides the values:
 constexpr int UNI_NONE = 0;     // values only
 constexpr int UNI_INLINE = 1;   // values + tiers 1 and 2 (small batches, the device sampler)

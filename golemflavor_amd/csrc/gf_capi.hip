@@ -704,6 +704,7 @@ int gf_model_create(const gf_model_desc* d, int device, gf_model** out)
             b.uni_lo_nl = 1e-7 * 2048.0 * std::pow(10.0, -lo_nl_dec);
             if (gf_internal_env("GF_UNI_NO_WEIGHT_GATE", 1)) b.uni_a_ok = 2.0;              // diagnostics: tier 1 off
             if (const char* e = gf_internal_env("GF_UNI_A_OK", 1)) b.uni_a_ok = std::atof(e);  // diagnostics: tier 1's threshold
+            b.uni_own_bins_only = gf_internal_env("GF_UNI_OWN_BINS_ONLY", 1) ? 1 : 0;             // diagnostics: A/B of uni_arbitration_mask
             if (gf_internal_env("GF_UNI_DUMP", 1)) { b.uni_lo = b.uni_lo_nl = -1.0; b.uni_hi = 1e300; }   // diagnostics: fr[0] <- the estimate
         }
         // per-model matrices of the unitarity arbitration, in the reference's own operation order

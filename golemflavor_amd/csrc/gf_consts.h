@@ -46,7 +46,7 @@ struct GfBsm {
     int32_t texture;
     int32_t dimension;
     int32_t nbins;
-    int32_t pad_;
+    int32_t uni_own_bins_only;     // diagnostics (GF_UNI_OWN_BINS_ONLY): the arbitration gets the undecided bins alone, not the bins above them
     // Fixed textures (fr.py:370-378): U~ diag(0, sc1, sc2) U~^dagger = sc1 T1 + sc2 T2 with the rank-1
     // projectors T1 = u~_1 u~_1^dagger, T2 = u~_2 u~_2^dagger (columns 1 and 2 of U~), precomputed in
     // long double on the host.  For texture NONE they are rebuilt per walker from the sampled angles.

@@ -119,7 +119,7 @@ __device__ __forceinline__ double proposal_lnprob(const GfCommon& c, const GfBsm
             UniAcc acc = {0.0, 0.0, 0ull, 2.0};
             flux_average<UNI_INLINE, LPW>(c, tb, ttab, row, fr, acc, sub, fgrp);
             st = (acc.clear_max < tb->uni_hi) ? ST_OK : ST_NON_UNITARY;       // tiers 1 and 2 (gf_bsm_device.hpp)
-            pending = st == ST_OK ? acc.amb : 0ull;
+            pending = st == ST_OK ? uni_arbitration_mask(acc.amb, tb) : 0ull;
             val = lp + gauss_llh(c, fr);
             if (val != val && st == ST_OK) st = ST_NAN;
         }

@@ -126,3 +126,66 @@ print("BAD", bad, "|" + _lib.diagnostic_overrides())
     assert res.returncode == 0, res.stderr[-3000:]
     last = res.stdout.strip().splitlines()[-1]
     assert last.startswith("BAD 0 |") and "GF_UNI_BAND_DECADES=12" in last, res.stdout
+
+
+_TIER_CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from test_gpu_unitarity_r3 import tier_cases, tier_statuses
+out = {}
+for name, st in tier_statuses(tier_cases()):
+    out[name] = st
+np.savez(sys.argv[2], **out)
+from golemflavor_amd import _lib
+print("OVERRIDES", _lib.diagnostic_overrides())
+'''
+
+
+def tier_cases():
+    # the failing region of the reference's assert is reached with OEU from d = 5 and OUT from d = 6; the others stay unitary
+    return [(6, Texture.OEU, True), (5, Texture.OEU, True), (7, Texture.OEU, True), (8, Texture.OEU, True), (6, Texture.OUT, True),
+            (8, Texture.OUT, True), (6, Texture.OET, False), (3, Texture.OUT, False), (4, Texture.OEU, False)]
+
+
+def tier_statuses(cases, n=100000):
+    """Statuses of n walkers per case, the scale over the whole SCALE_BOUNDARIES range (so that every tier sees walkers:
+    SM-weight acquittals at low scales, the fp64 estimate's two cut-offs, the band in between)."""
+    for dim, tex, twelve in cases:
+        ps = Cf.fr_paramsets(dim, (0.4, 0.0))[1] if twelve else Cf.texture_paramset(dim)
+        lo, hi = Cf.SCALE_BOUNDARIES[dim]
+        rng = np.random.default_rng(1000 + dim)
+        th = uniform_theta(ps, n, rng, seeds=True)
+        th[:, -1] = rng.uniform(lo, hi, n)
+        kw = dict(dimension=dim, binning=BIN_EDGES, source_ratio=(0., 1., 0.), bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+        with Model(compile_model(ps, "BSM_GAUSS", texture=tex, **kw)) as m:
+            _, st = m.lnprob(th)
+        yield "d%d_%s_%d" % (dim, tex.name, twelve), st
+
+
+def test_the_cheap_tiers_never_overrule_the_x87_chain(tmp_path):
+    """Tier 1 (SM-weight bound: acquits without evaluating anything) and tier 2 (fp64 estimate: acquits below the band,
+    condemns above it) rest on margins measured on samples (DESIGN section 5).  Here 900 000 walkers over the whole scale
+    range of nine (dimension, texture) cases get their status twice: as shipped, and in a child process where every walker
+    is sent through the emulated-x87 chain (GF_UNI_NO_WEIGHT_GATE + a 12-decade band, result-changing overrides that need
+    GF_DIAGNOSTICS=1 and are echoed).  The two must be identical: no tier settles a walker the exact chain would settle the
+    other way.  (Before the arbitration took every bin above the lowest undecided one -- uni_arbitration_mask -- 21 of
+    2.4 M walkers differed here, all with one failing bin at 1.03e-7 ... 1.42e-7: profiles/r03/tier2_pairs.txt.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script, out = tmp_path / "child.py", tmp_path / "st.npz"
+    script.write_text(_TIER_CHILD)
+    env = dict(os.environ, GF_DIAGNOSTICS="1", GF_UNI_BAND_DECADES="12", GF_UNI_NO_WEIGHT_GATE="1", PYTHONDONTWRITEBYTECODE="1")
+    res = subprocess.run([sys.executable, str(script), root, str(out)], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "GF_UNI_BAND_DECADES=12" in res.stdout and "GF_UNI_NO_WEIGHT_GATE=1" in res.stdout
+    exact = np.load(out)
+    assert "GF_UNI_" not in _lib.diagnostic_overrides()            # this process runs the tiers as shipped
+    nbad = nnon = 0
+    for name, st in tier_statuses(tier_cases()):
+        nbad += int(np.sum(st != exact[name]))
+        nnon += int(np.sum(exact[name] == _lib.GF_ST_NON_UNITARY))
+        assert np.array_equal(st, exact[name]), (name, int(np.sum(st != exact[name])))
+    assert nnon > 100000                                           # the failing region is well represented
