@@ -171,7 +171,10 @@ int gf_haar_draw(gf_model* m, uint64_t seed, int64_t first_draw, int64_t n, doub
 int gf_device_alloc(gf_model* m, size_t bytes, void** dptr);
 int gf_device_free(gf_model* m, void* dptr);
 int gf_memcpy_h2d(gf_model* m, void* dst_dev, const void* src_host, size_t bytes);  /* async + sync */
-int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes);  /* async + sync */
+/* Synchronous.  From 16 MB on the copy brings its own staging: eight pinned 16 MB slots per device (allocated on first
+ * use), filled by the DMA engine while host threads empty the earlier ones into dst_host -- so the rate (43-49 GB/s
+ * measured) does not depend on whether dst_host is pinned, touched or fresh memory. */
+int gf_memcpy_d2h(gf_model* m, void* dst_host, const void* src_dev, size_t bytes);
 /* asynchronous on the model's stream; `layout` is a gf_layout */
 int gf_lnprob_batch_device(gf_model* m, const double* d_theta, int layout, int64_t n,
                            double* d_lnprob, double* d_fr, int32_t* d_status);
@@ -186,8 +189,8 @@ int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int n
 int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uint64_t* counts);
 int gf_model_sync(gf_model* m);
 /* Touch the pages of a freshly allocated host buffer (content clobbered) from several threads, so that a following
- * large device-to-host copy (gf_sampler_get_chain, gf_memcpy_d2h: sampler.chain of golemflavor/mcmc.py:43) runs at
- * PCIe speed instead of page-fault speed. */
+ * large device-to-host copy (gf_sampler_get_chain: sampler.chain of golemflavor/mcmc.py:43) runs at PCIe speed instead of
+ * page-fault speed.  (gf_memcpy_d2h and gf_sampler_postprocess_rows do not need it: their staging threads map the pages.) */
 int gf_host_prepare(void* buf, size_t bytes);
 
 /* HIP events on the model's stream (what bench.py times the kernel with) */
