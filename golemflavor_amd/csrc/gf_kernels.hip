@@ -57,8 +57,25 @@ using namespace gfdev;
 #ifndef GF_SM_WAVES_PER_EU
 #define GF_SM_WAVES_PER_EU 4
 #endif
+// Waves per SIMD the kernels are compiled for: four (128 VGPRs) wherever the instance fits -- the bench kernel uses 48 --; the
+// instances that spill at four get the registers instead.  Measured (tools/bench_sm12.py, 16.8 M walkers, profiles/r03/
+// ab_wide_sm_instances.txt): the 12-column flavor likelihood from AoS rows 1.38 ms at four waves (144-272 B of scratch per
+// lane), 0.469 ms at three (32-112 B), 0.302 ms at two (none) = 0.16 / 0.47 / 0.72 of HBM peak; 12 prior columns from an SoA
+// buffer 0.782 / 0.375 / 0.311 ms.  So: two waves for 12 columns with the likelihood or from SoA, three for the generic-column
+// (SAMPLED = 0) likelihood instances from 6 / 7 columns on (32-96 B at four).
+#ifndef GF_SM_WIDE_WAVES_PER_EU
+#define GF_SM_WIDE_WAVES_PER_EU 2
+#endif
+template <int NDIM, int MODE, int SAMPLED, bool SOA>
+constexpr int sm_waves_per_eu()
+{
+    constexpr int most = GF_SM_WAVES_PER_EU;
+    if (NDIM >= 12 && (MODE == MODE_SM_GAUSS || SOA)) return most < GF_SM_WIDE_WAVES_PER_EU ? most : GF_SM_WIDE_WAVES_PER_EU;
+    if (SAMPLED == 0 && MODE == MODE_SM_GAUSS && NDIM >= 6 && (SOA || NDIM >= 7)) return most < 3 ? most : 3;
+    return most;
+}
 template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
-__global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast(const GfCommon c, const double* __restrict__ ptab,
+__global__ __launch_bounds__(GF_BLOCK, (sm_waves_per_eu<NDIM, MODE, SAMPLED, false>())) void k_lnprob_sm_fast(const GfCommon c, const double* __restrict__ ptab,
                                                               const double* __restrict__ theta, int64_t nfull,
                                                               double* __restrict__ lnprob, double* __restrict__ fr_out,
                                                               int32_t* __restrict__ status)
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_fast
 // (canonical columns: the row registers are used by position) or 0 for MODE_PRIOR_ONLY; posteriors that read named
 // columns through a runtime index stay on the generic kernel (a register array cannot be indexed dynamically).
 template <int NDIM, int MODE, int SAMPLED, bool WANT_FR>
-__global__ __launch_bounds__(GF_BLOCK, GF_SM_WAVES_PER_EU) void k_lnprob_sm_soa(const GfCommon c, const double* __restrict__ ptab,
+__global__ __launch_bounds__(GF_BLOCK, (sm_waves_per_eu<NDIM, MODE, SAMPLED, true>())) void k_lnprob_sm_soa(const GfCommon c, const double* __restrict__ ptab,
                                                              const double* __restrict__ theta, int64_t n, int64_t nfull,
                                                              double* __restrict__ lnprob, double* __restrict__ fr_out,
                                                              int32_t* __restrict__ status)

@@ -326,9 +326,10 @@ struct PersistArgs {
     const uint64_t* stream_ids;     // as StretchArgs::stream_ids
 };
 
-// MAXT: the largest workgroup the instance is compiled for.  1024 threads cap the kernel at 128 VGPRs, which the canonical
-// posterior overflows by a few (32-256 B of scratch per lane inside the step loop); ensembles of up to 512 walkers (the
-// reference's 100-walker chain runs on ONE wave) take the 256-thread instance, which has the registers it wants.
+// MAXT: the largest workgroup the instance is compiled for.  1024 threads would cap the kernel at 128 VGPRs, which the
+// likelihood instances overflow (32-256 B of scratch per lane inside the step loop, round 2); workgroups are at most 512 threads
+// (two waves per SIMD, up to 256 VGPRs; the instances use 57-195) and a larger half-ensemble takes two or more passes of the loop
+// over k.  The reference's 100-walker chain runs on ONE wave.
 template <int NDIM, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
 {
@@ -417,7 +418,8 @@ inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds)
 {
     const int nhalf = nwalkers / 2;
     int nt = ((nhalf + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
-    if (nt > 1024) nt = 1024;
+    if (nt > 512) nt = 512;       // a workgroup of 1024 threads is capped at 128 VGPRs, which the likelihood instances overflow (32-256 B of
+                                  // scratch per lane inside the step loop); the half-ensemble loop strides by the block size anyway
     const size_t bytes = sizeof(double) * ((size_t)GF_MAX_DIM * 4 + (size_t)nwalkers * ndim + nwalkers + (size_t)nt * ndim) +
                          sizeof(uint32_t) * (size_t)nwalkers;
     *threads = nt;
@@ -429,10 +431,10 @@ hipError_t launch_persist_n(int mode, int nchains, int threads, size_t lds, cons
 {
     if (mode == MODE_PRIOR_ONLY) {
         if (threads <= 256) hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY, 256>), dim3(nchains), dim3(threads), lds, st, a);
-        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY, 1024>), dim3(nchains), dim3(threads), lds, st, a);
+        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_PRIOR_ONLY, 512>), dim3(nchains), dim3(threads), lds, st, a);
     } else {
         if (threads <= 256) hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS, 256>), dim3(nchains), dim3(threads), lds, st, a);
-        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS, 1024>), dim3(nchains), dim3(threads), lds, st, a);
+        else hipLaunchKernelGGL((k_stretch_persist<NDIM, MODE_SM_GAUSS, 512>), dim3(nchains), dim3(threads), lds, st, a);
     }
     return hipGetLastError();
 }
