@@ -1409,6 +1409,17 @@ int gf_device_trim(int device, size_t* released_bytes)
         DevicePool& dp = g_pool[device];
         for (hipStream_t st : streams) dp.streams.push_back(st);
     }
+    // the pinned staging slots of large device-to-host reads (host memory: not part of released_bytes, which counts device
+    // memory); a read in progress keeps them
+    {
+        D2HRing& R = g_d2h[device];
+        std::unique_lock<std::mutex> lk(R.mu, std::try_to_lock);
+        if (lk.owns_lock())
+            for (int k = 0; k < D2H_SLOTS; ++k) {
+                if (R.slot[k]) { (void)hipHostFree(R.slot[k]); R.slot[k] = nullptr; }
+                if (R.ev[k]) { (void)hipEventDestroy(R.ev[k]); R.ev[k] = nullptr; }
+            }
+    }
     if (released_bytes) *released_bytes = total;
     return GF_OK;
 }

@@ -30,6 +30,30 @@ from .enums import Texture
 from .model import Model
 
 
+def _patched(template, **fields):
+    """A copy of a compiled descriptor with some of its plain fields replaced.  The grid points of a scan differ from one
+    another in the source ratio, the texture and the fixed scale only -- fields `compile_model` copies through without
+    deriving anything from them -- so a scan compiles one descriptor per (paramset, dimension) and patches it per point
+    (50 us per point saved; `tests/test_host_logic.py` holds the patched copy to the freshly compiled one byte for byte)."""
+    d = type(template).from_buffer_copy(template)
+    for name, value in fields.items():
+        if name == "source_ratio":
+            for k in range(3):
+                d.source_ratio[k] = float(value[k])
+        elif name == "texture":
+            d.texture = value.value if isinstance(value, Texture) else int(value)
+            if d.texture == Texture.NONE.value:               # compile_model checks the NP-angle columns for that one
+                raise ValueError("Texture.NONE is compiled, not patched")
+        elif name == "scale_fixed":
+            d.scale_fixed = float(value)
+        else:
+            raise KeyError(name)
+    return d
+
+
+_BIN_EDGES = Cf.default_bin_edges()
+
+
 def texture_grid(dimension=6, n_scales=8, n_sources=8):
     """C4: 8 logLam (linspace over SCALE_BOUNDARIES[d]) x 8 sources (x, 1-x, 0)."""
     lo, hi = Cf.SCALE_BOUNDARIES[dimension]
@@ -44,16 +68,29 @@ class _TexturePoint:
 
     def __init__(self, point, g, *, dimension, texture, nwalkers, device, seed=25):
         self.scale, self.source = point
-        self.ps6 = Cf.ParamSet(list(Cf.texture_paramset(dimension))[:6])       # scale fixed per grid point
-        self.f = llh_utils.prior_ln_prob(self.ps6, device=device)
+        self.ps6, box, prior_desc, post_desc = self.descriptors(point, dimension, texture)
+        self.f = llh_utils.LnProb(prior_desc, device=device)   # llh.prior_ln_prob(ps6): mc_texture.py:161-170
         rng = np.random.default_rng(seed + g)
-        box = np.array(self.ps6.seeds, dtype=float)
         self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 6))        # mcmc.flat_seed, seeded per point
         self.ndim, self.nwalkers, self.seed = 6, nwalkers, seed + g
-        desc = compile_model(self.ps6, "BSM_GAUSS", texture=texture, dimension=dimension,
-                             binning=Cf.default_bin_edges(), source_ratio=self.source, scale_fixed=self.scale,
-                             bestfit_fr=(1 / 3,) * 3, smearing=0.02)
-        self.post_model = Model(desc, device=device)           # the chain is propagated with this one, on the device
+        self.post_model = Model(post_desc, device=device)      # the chain is propagated with this one, on the device
+
+    _templates = {}
+
+    @classmethod
+    def descriptors(cls, point, dimension, texture):
+        """(paramset of the chain, its seed box, descriptor of the prior chain, descriptor of the point's flux average)"""
+        scale, source = point
+        tex = texture if isinstance(texture, Texture) else Texture(texture)
+        key = (dimension, tex)
+        if key not in cls._templates:                          # the same for every grid point: compiled once
+            ps6 = Cf.ParamSet(list(Cf.texture_paramset(dimension))[:6])        # scale fixed per grid point
+            cls._templates[key] = (ps6, np.array(ps6.seeds, dtype=float), compile_model(ps6, "PRIOR_ONLY", flat_llh=1.0),
+                                   compile_model(ps6, "BSM_GAUSS", texture=tex, dimension=dimension, binning=_BIN_EDGES,
+                                                 source_ratio=(1.0, 0.0, 0.0), scale_fixed=0.0, bestfit_fr=(1 / 3,) * 3,
+                                                 smearing=0.02))
+        ps6, box, prior_desc, post = cls._templates[key]
+        return ps6, box, prior_desc, _patched(post, source_ratio=source, scale_fixed=scale)
 
     @staticmethod
     def assemble(samples, frs, status):
@@ -95,13 +132,9 @@ class _SensPoint:
 
     def __init__(self, point, g, *, nwalkers, device, seed=25, smearing=0.02):
         dim, tex, source, scale = point
-        if dim not in self._paramsets:                        # the same for every grid point of a dimension; read-only here
-            self._paramsets[dim] = Cf.fr_paramsets(dim, fr_utils.fr_to_angles((1, 1, 1)))
-        asimov, ps = self._paramsets[dim]
-        args = argparse.Namespace(source_ratio=np.array(source), dimension=dim, texture=tex, binning=Cf.default_bin_edges())
-        self.f = llh_utils.bsm_ln_prob(args, asimov, ps, smearing=smearing, device=device, on_nonunitary="-inf")
+        ps, box, desc = self.descriptor(point, smearing)
+        self.f = llh_utils.LnProb(desc, device=device, on_nonunitary="-inf")
         rng = np.random.default_rng(seed + g)
-        box = np.array(ps.seeds, dtype=float)
         self.p0 = rng.uniform(box[:, 0], box[:, 1], size=(nwalkers, 12))
         lo, hi = Cf.SCALE_BOUNDARIES[dim]
         self.p0[:, 11] = np.clip(rng.normal(scale, 0.5, nwalkers), lo, hi)
@@ -109,6 +142,21 @@ class _SensPoint:
 
     post_model = None
     _paramsets = {}
+
+    @classmethod
+    def descriptor(cls, point, smearing=0.02):
+        """(paramset, its seed box, descriptor) of the point: llh.bsm_ln_prob(args, asimov, ps, smearing)'s, the template
+        compiled once per dimension"""
+        dim, tex, source, scale = point
+        key = (dim, smearing)
+        if key not in cls._paramsets:                         # the same for every grid point of a dimension; read-only here
+            asimov, ps = Cf.fr_paramsets(dim, fr_utils.fr_to_angles((1, 1, 1)))
+            bf = fr_utils.angles_to_fr(asimov.from_tag(llh_utils.ParamTag.BESTFIT, values=True))
+            template = compile_model(ps, "BSM_GAUSS", bestfit_fr=bf, smearing=smearing, source_ratio=(1.0, 0.0, 0.0),
+                                     texture=Texture.OET, dimension=dim, binning=_BIN_EDGES)
+            cls._paramsets[key] = (asimov, ps, np.array(ps.seeds, dtype=float), template)
+        asimov, ps, box, template = cls._paramsets[key]
+        return ps, box, _patched(template, source_ratio=source, texture=tex)
 
     @staticmethod
     def assemble(samples, frs, status):

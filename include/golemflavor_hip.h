@@ -131,7 +131,8 @@ size_t gf_sizeof_model_desc(void);     /* sizeof(gf_model_desc) as compiled: let
 int gf_diagnostic_overrides(char* buf, size_t buflen);
 int gf_device_count(int* count);
 /* ABI 3.  Hand back the device memory the library caches between uses on `device`: the unitarity workspaces of idle pooled
- * streams (up to 8 GiB) and pooled constant blocks.  *released_bytes may be NULL. */
+ * streams (up to 8 GiB) and pooled constant blocks -- *released_bytes (may be NULL) counts these -- and the 128 MB of pinned
+ * host staging slots of gf_memcpy_d2h. */
 int gf_device_trim(int device, size_t* released_bytes);
 int gf_device_name(int device, char* buf, size_t buflen);   /* gcnArchName, e.g. "gfx950:..."   */
 

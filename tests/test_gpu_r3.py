@@ -161,3 +161,4 @@ def test_large_reads_come_back_through_the_pinned_ring_intact():
             _lib.check(_lib.lib().gf_memcpy_d2h(m._h, back[3:].ctypes.data, d.ptr, nbytes), "d2h")
             assert np.array_equal(back[3:].view(np.int64), src.view(np.int64)), nbytes
             d.free()
+            _lib.device_trim(0)                                  # frees the pinned slots too: the next large read allocates them again

@@ -366,3 +366,34 @@ def test_result_changing_overrides_need_gf_diagnostics(tmp_path):
     assert out.stdout.strip() == "None b'4' |GF_UNI_A_OK(ignored) GF_SAMPLER_LPW=4" and "ignored" in out.stderr
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GF_DIAGNOSTICS="1"), timeout=60)
     assert out.stdout.strip() == "b'1e-9' b'4' |GF_UNI_A_OK=1e-9 GF_SAMPLER_LPW=4"
+
+
+def test_scan_point_descriptors_are_the_compiled_ones():
+    """A grid scan compiles one descriptor per (paramset, dimension) and patches source ratio / texture / fixed scale per
+    point (scan._patched).  Every point's patched descriptor must be, byte for byte, what the reference-shaped entry points
+    compile for that point on their own: llh.bsm_ln_prob's descriptor (C5), mc_texture.py's two models (C4)."""
+    import argparse
+    from golemflavor_amd import scan, fr as fr_utils
+    from golemflavor_amd.enums import ParamTag
+    for point in scan.sens_grid():
+        dim, tex, source, scale = point
+        ps, box, got = scan._SensPoint.descriptor(point, 0.02)
+        asimov, ps_ref = Cf.fr_paramsets(dim, fr_utils.fr_to_angles((1, 1, 1)))
+        bf = fr_utils.angles_to_fr(asimov.from_tag(ParamTag.BESTFIT, values=True))
+        want = compile_model(ps_ref, "BSM_GAUSS", bestfit_fr=bf, smearing=0.02, source_ratio=np.array(source), texture=tex,
+                             dimension=dim, binning=Cf.default_bin_edges(), no_bsm=False)
+        assert bytes(got) == bytes(want), point
+        assert np.array_equal(box, np.array(ps_ref.seeds, dtype=float))
+    for tex in (Texture.OET, Texture.OEU):
+        for point in scan.texture_grid(6):
+            scale, source = point
+            ps6, box, prior, post = scan._TexturePoint.descriptors(point, 6, tex)
+            ref6 = Cf.ParamSet(list(Cf.texture_paramset(6))[:6])
+            assert bytes(prior) == bytes(compile_model(ref6, "PRIOR_ONLY", flat_llh=1.0))
+            want = compile_model(ref6, "BSM_GAUSS", texture=tex, dimension=6, binning=Cf.default_bin_edges(), source_ratio=source,
+                                 scale_fixed=scale, bestfit_fr=(1 / 3,) * 3, smearing=0.02)
+            assert bytes(post) == bytes(want), point
+    with pytest.raises(ValueError):
+        scan._patched(post, texture=Texture.NONE)
+    with pytest.raises(KeyError):
+        scan._patched(post, dimension=4)
