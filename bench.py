@@ -318,6 +318,8 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
         local = dict(scan.PHASES)
         local.update({k: v for k, v in g.stats.items() if isinstance(v, (int, float)) and k not in ("ranks", "slots_per_rank")})
         gather_kind = "rccl gather to rank 0 over xGMI (gf_comm_gather), one download" if rccl is not None else "device -> host (one rank)"
+        if g.stats.get("note"):
+            gather_kind += ": " + g.stats["note"]
     else:
         # no communicator (reported in the line as rccl_error): the blocks go to rank 0 through the host control plane
         loc = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True)

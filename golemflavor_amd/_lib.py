@@ -91,6 +91,7 @@ SIGNATURES = {
     "gf_sampler_set_state": (C.c_int, [_vp, _dp]),
     "gf_sampler_run": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int]),
     "gf_sampler_sync": (C.c_int, [_vp]),
+    "gf_sampler_run_to_host": (C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp, _dp]),
     "gf_sampler_reset": (C.c_int, [_vp]),
     "gf_sampler_nstored": (C.c_int64, [_vp]),
     "gf_sampler_iterations": (C.c_int64, [_vp]),

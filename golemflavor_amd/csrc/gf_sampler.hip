@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -536,6 +537,12 @@ struct gf_sampler {
     double* graph_lnp_chain = nullptr;
     int64_t graph_cap = -1;
     int graph_has_chain = -1;
+    // gf_sampler_run_to_host: events recorded behind every block of steps of the run in flight, with the number of stored steps
+    // that are final once the event has passed
+    bool marking = false;
+    hipEvent_t* mark_events = nullptr;
+    int64_t* mark_nstored = nullptr;
+    int nmarks = 0, mark_cap = 0;
 };
 
 // accessors implemented in gf_capi.hip (gf_model is private to it)
@@ -555,6 +562,8 @@ int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int 
 int gf_internal_check_overflow(int device, void* stream);
 int gf_internal_d2h_gated(int device, void* stream, void* dst_host, const void* src_dev, size_t bytes,
                           int (*gate)(void* ctx, size_t upto), void* gate_ctx);
+int gf_internal_d2h_2d(int device, void* stream, void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width,
+                       size_t height);
 }
 
 namespace {
@@ -644,6 +653,9 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_pend_ctl) (void)hipFree(s->d_pend_ctl);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
+    for (int i = 0; i < s->mark_cap; ++i) if (s->mark_events[i]) (void)hipEventDestroy(s->mark_events[i]);
+    delete[] s->mark_events;
+    delete[] s->mark_nstored;
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
     if (s->d_commons) (void)hipFree(s->d_commons);
@@ -770,6 +782,26 @@ int gf_sampler_reset(gf_sampler* s)
     s->steps_since_reset = 0;
     return GF_OK;
 }
+
+namespace {
+// an event behind what has been enqueued so far; `nstored` stored steps of every chain are final once it has passed
+void mark_block(gf_sampler* s, hipStream_t st, int64_t nstored)
+{
+    if (s->nmarks == s->mark_cap) {
+        const int cap = s->mark_cap ? 2 * s->mark_cap : 64;
+        hipEvent_t* ev = new (std::nothrow) hipEvent_t[cap]();
+        int64_t* ns = new (std::nothrow) int64_t[cap]();
+        if (!ev || !ns) { delete[] ev; delete[] ns; return; }          // no mark: the block is copied with the next one
+        for (int i = 0; i < s->mark_cap; ++i) { ev[i] = s->mark_events[i]; ns[i] = s->mark_nstored[i]; }
+        delete[] s->mark_events; delete[] s->mark_nstored;
+        s->mark_events = ev; s->mark_nstored = ns; s->mark_cap = cap;
+    }
+    hipEvent_t& e = s->mark_events[s->nmarks];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); return; }
+    if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); return; }
+    s->mark_nstored[s->nmarks++] = nstored;
+}
+}  // namespace
 
 // Advance every ensemble by nsteps stretch-move steps (2 launches each), asynchronously on the model's
 // stream.  store != 0 appends every `thin`-th step to the device chain (capacity grows as needed).
@@ -920,6 +952,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             hipError_t e = hipGraphLaunch(s->graph, st);
             if (e != hipSuccess) return sfail(e, "hipGraphLaunch");
             done += GRAPH_STEPS;
+            if (s->marking && store) mark_block(s, st, hs.store_base + (done + thin - 1) / thin);
         }
     }
     while (done < nsteps) {
@@ -927,6 +960,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         hipError_t e = steps(count);
         if (e != hipSuccess) return sfail(e, "stretch launch");
         done += count;
+        if (s->marking && store) mark_block(s, st, hs.store_base + (done + thin - 1) / thin);
     }
     s->iteration += (uint64_t)nsteps;
     s->steps_since_reset += nsteps;
@@ -938,6 +972,58 @@ int gf_sampler_sync(gf_sampler* s)
 {
     if (!s) return GF_ERR_INVALID_ARG;
     return gf_model_sync(s->model);
+}
+
+// gf_sampler_run(..., store = 1) with the read-back of the chain overlapped: the run is enqueued as usual (asynchronously, an
+// event behind every block of 16 steps), and while the GPU works through it this thread copies every finished block of steps
+// of all chains to the host on a second stream, through the library's pinned ring.  On return the run is complete and
+// chain [nchains][nstored][nwalkers][ndim] / lnprob_chain [nchains][nstored][nwalkers] (may be NULL) hold the WHOLE stored chain
+// (steps stored by earlier runs included).  What sampler.chain needs after run_mcmc (golemflavor/mcmc.py:41-43), without the
+// wait for the read-back at the end.  *readback_tail_s (may be NULL): seconds between the end of the run on the GPU and the end of
+// the last copy -- what of the read-back was NOT hidden behind the run.
+int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chain, double* lnprob_chain, double* readback_tail_s)
+{
+    if (!s || !chain || nsteps < 0 || thin < 1) return GF_ERR_INVALID_ARG;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipSetDevice(device));
+    s->marking = true;
+    s->nmarks = 0;
+    int rc = gf_sampler_run(s, nsteps, thin, 1);
+    s->marking = false;
+    if (rc != GF_OK) return rc;
+    const int64_t total = s->nstored;                                   // after the run
+    void* copy_stream = nullptr;
+    rc = gf_internal_borrow_stream(device, &copy_stream);
+    if (rc != GF_OK) { (void)hipStreamSynchronize((hipStream_t)stream); return rc; }
+    const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
+    int64_t prev = 0;
+    hipError_t e = hipSuccess;
+    auto t_done = std::chrono::steady_clock::now();                     // when the run itself was complete on the GPU
+    for (int m = 0; m <= s->nmarks && rc == GF_OK && e == hipSuccess; ++m) {
+        int64_t upto;
+        if (m < s->nmarks) { e = hipEventSynchronize(s->mark_events[m]); upto = s->mark_nstored[m]; }
+        else { e = hipStreamSynchronize((hipStream_t)stream); upto = total; t_done = std::chrono::steady_clock::now(); }   // whatever no mark covered
+        if (e != hipSuccess || upto <= prev) continue;
+        if (upto > total) upto = total;
+        const size_t steps_now = (size_t)(upto - prev);
+        rc = gf_internal_d2h_2d(device, copy_stream, reinterpret_cast<char*>(chain) + row * (size_t)prev, row * (size_t)total,
+                                reinterpret_cast<const char*>(s->d_chain) + row * (size_t)prev, row * (size_t)s->nstore_cap,
+                                row * steps_now, (size_t)s->nchains);
+        if (rc == GF_OK && lnprob_chain)
+            rc = gf_internal_d2h_2d(device, copy_stream, reinterpret_cast<char*>(lnprob_chain) + lrow * (size_t)prev, lrow * (size_t)total,
+                                    reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * (size_t)prev, lrow * (size_t)s->nstore_cap,
+                                    lrow * steps_now, (size_t)s->nchains);
+        prev = upto;
+    }
+    const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)copy_stream);
+    gf_internal_return_stream(device, copy_stream);
+    if (readback_tail_s) *readback_tail_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_done).count();
+    if (rc != GF_OK) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return sfail(e, "gf_sampler_run_to_host");
+    return GF_OK;
 }
 
 int64_t gf_sampler_nstored(const gf_sampler* s) { return s ? s->nstored : -1; }

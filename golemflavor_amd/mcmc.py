@@ -271,6 +271,30 @@ class DeviceEnsembleSampler:
         pos, lnp = self.state
         return pos, lnp, None
 
+    def run_mcmc_to_host(self, pos0, N, thin=1, lnprob=False, out=None):
+        """run_mcmc(pos0, N, thin) with the chain's read-back overlapped with the run (gf_sampler_run_to_host): every finished
+        block of steps crosses PCIe while the GPU computes the next ones.  Returns the stored chain in the device's order,
+        (nchains, nstored, nwalkers, ndim) [and the lnprob chain, (nchains, nstored, nwalkers)] -- `flat_steps()` /
+        `chain` of the same run, already on the host."""
+        if pos0 is not None:
+            self._set_state(pos0)
+        if not self._have_state:
+            raise ValueError("no starting position")
+        thin = int(thin)
+        ns = int(self._L.gf_sampler_nstored(self._h)) + (int(N) + thin - 1) // thin
+        c = np.empty((self.nchains, ns, self.k, self.dim)) if out is None else out
+        if c.shape != (self.nchains, ns, self.k, self.dim) or c.dtype != np.float64 or not c.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %r" % ((self.nchains, ns, self.k, self.dim),))
+        lnp = np.empty((self.nchains, ns, self.k)) if lnprob else None
+        tail = self._C.c_double(0.0)
+        self._lib.check(self._L.gf_sampler_run_to_host(self._h, int(N), thin, c.ctypes.data_as(self._lib._dp),
+                                                       lnp.ctypes.data_as(self._lib._dp) if lnprob else None,
+                                                       self._C.byref(tail)),
+                        "gf_sampler_run_to_host")
+        self.readback_tail_s = float(tail.value)          # what of the read-back was not hidden behind the run
+        self._check_flags()
+        return (c, lnp) if lnprob else c
+
     def run_async(self, pos0, N, thin=1, storechain=True):
         """Enqueue N steps on the model's stream and return immediately; pair with `wait()`.  Samplers of
         different models live on different streams, so several small ensembles overlap on the GPU."""
@@ -435,7 +459,7 @@ class DeviceEnsembleSampler:
             handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
         self._lib.check(self._L.gf_sampler_postprocess_rows_device(self._h, handles, d_rows), "gf_sampler_postprocess_rows_device")
 
-    def postprocess_rows(self, models=None):
+    def postprocess_rows(self, models=None, out=None):
         """The same rows on the host, (nchains, nstored * nwalkers, 3 + ndim): the finished chains cross PCIe while the later
         ones are still being post-processed."""
         C = self._C
@@ -444,7 +468,10 @@ class DeviceEnsembleSampler:
             ms = [getattr(m, "model", m) for m in models]
             handles = (C.c_void_p * self.nchains)(*[m._h.value if hasattr(m._h, "value") else m._h for m in ms])
         ns = int(self._L.gf_sampler_nstored(self._h))
-        out = np.empty((self.nchains, ns * self.k, 3 + self.dim))
+        if out is None:
+            out = np.empty((self.nchains, ns * self.k, 3 + self.dim))
+        if out.shape != (self.nchains, ns * self.k, 3 + self.dim) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %r" % ((self.nchains, ns * self.k, 3 + self.dim),))
         self._lib.check(self._L.gf_sampler_postprocess_rows(self._h, handles, out.ctypes.data_as(self._lib._dp)),
                         "gf_sampler_postprocess_rows")
         return out

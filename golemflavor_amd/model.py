@@ -26,6 +26,28 @@ def empty_for_download(shape, dtype=np.float64, copier_maps_pages=False):
     return out
 
 
+class Prefaulted:
+    """A result array allocated AHEAD of the device work that fills it, its pages mapped by a background thread
+    (gf_host_prepare releases the GIL) while the GPU is busy with that work -- a grid scan knows the size of its result
+    before the burn-in starts, and the host has nothing else to do until the chain is ready.  `get()` joins the thread."""
+
+    def __init__(self, shape, dtype=np.float64):
+        import threading
+        self.array = np.empty(shape, dtype=dtype)
+        self._t = None
+        if self.array.nbytes >= PREPARE_MIN_BYTES:
+            L = _lib.lib()
+            ptr, nbytes = self.array.ctypes.data_as(C.c_void_p), self.array.nbytes
+            self._t = threading.Thread(target=lambda: L.gf_host_prepare(ptr, nbytes), daemon=True)
+            self._t.start()
+
+    def get(self):
+        if self._t is not None:
+            self._t.join()
+            self._t = None
+        return self.array
+
+
 def _as_theta(theta, ndim):
     th = np.ascontiguousarray(theta, dtype=np.float64)
     if th.ndim == 1:
@@ -54,8 +76,10 @@ class DeviceBuffer:
         check(self.model._L.gf_memcpy_h2d(self.model._h, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes), "h2d")
         return self
 
-    def download(self, shape, dtype=np.float64, offset_bytes=0):
-        out = empty_for_download(shape, dtype, copier_maps_pages=True)
+    def download(self, shape, dtype=np.float64, offset_bytes=0, out=None):
+        if out is None:
+            out = empty_for_download(shape, dtype, copier_maps_pages=True)
+        assert out.shape == tuple(shape) and out.dtype == np.dtype(dtype) and out.flags.c_contiguous
         assert out.nbytes + offset_bytes <= self.nbytes
         src = C.c_void_p(self.ptr.value + offset_bytes)
         check(self.model._L.gf_memcpy_d2h(self.model._h, out.ctypes.data_as(C.c_void_p), src, out.nbytes), "d2h")

@@ -27,7 +27,7 @@ from . import llh as llh_utils
 from . import mcmc as mcmc_utils
 from .descriptor import compile_model
 from .enums import Texture
-from .model import Model
+from .model import Model, Prefaulted
 
 
 def _patched(template, **fields):
@@ -197,9 +197,17 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed,
                                                    stream_ids=order)
         sampler.on_nonunitary = "-inf"
+        if gather is not None:
+            gather.prepare(first, len(order), len(points), nsteps)  # the result array: its pages are mapped while the GPU burns in
         sampler.run_mcmc(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
         sampler.reset()
-        sampler.run_mcmc(None, nsteps)
+        streamed = None
+        if gather is not None and gather.streams_chain(first):
+            # one rank, the chain is the result: its blocks of steps cross PCIe while the later ones are sampled
+            streamed = sampler.run_mcmc_to_host(None, nsteps, out=gather.destination((len(order), nsteps, first.nwalkers, first.ndim)))
+            gather.readback_tail_s = sampler.readback_tail_s
+        else:
+            sampler.run_mcmc(None, nsteps)
         PHASES["sampling"] = time.perf_counter() - t0
         # proposals of the stored run the reference would have died on (fr.py:493-498): rejected on the device, counted here
         LAST_NONUNITARY.clear()
@@ -207,7 +215,7 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
                                 "settled": "on the device, before the accept step (k_stretch_settle)"})
         t0 = time.perf_counter()
         if gather is not None:
-            out = gather.run(sampler, jobs, order, len(points))
+            out = gather.run(sampler, jobs, order, len(points), streamed=streamed)
             sampler.close()
             for j in jobs.values():
                 j.close()
@@ -258,11 +266,35 @@ class DeviceGather:
     def __init__(self, rccl, rank, world, model_for_buffers, root=0):
         self.rccl, self.rank, self.world, self.m, self.root = rccl, rank, world, model_for_buffers, root
         self.stats = {}
+        self._dest = None
+
+    def prepare(self, first_job, n_local, n_points, nsteps):
+        """Allocate the array the gathered chains will land in -- its size is known before the first step -- and have its
+        pages mapped in the background while the GPU samples (model.Prefaulted).  Only where this rank receives anything."""
+        per = nsteps * first_job.nwalkers
+        width = first_job.ndim if first_job.post_model is None else 3 + first_job.ndim
+        if self.streams_chain(first_job):
+            shape = (n_local, nsteps, first_job.nwalkers, first_job.ndim)
+        elif self.rccl is not None and self.rank == self.root:
+            shape = (self.world, gdist.slots_per_rank(n_points, self.world), per, width)
+        else:
+            # (one rank with post-processing, C4: the sampling takes 7-20 ms, less than mapping the pages does, and the page
+            # faults of 16 threads hold up the main thread's launches and allocations -- measured slower, profiles/r03/readback.txt)
+            return
+        self._dest = Prefaulted(shape)
+
+    def destination(self, shape):
+        """The prepared array if it has this shape (else None: the callee allocates)."""
+        d, self._dest = self._dest, None
+        if d is None:
+            return None
+        a = d.get()
+        return a if a.shape == tuple(shape) else None
 
     def _exchange(self, d_send, nbytes, shape, dtype):
         if self.rccl is None:
             t0 = time.perf_counter()
-            out = d_send.download(shape[1:], dtype=dtype)[None] if self.rank == self.root else None
+            out = d_send.download(shape[1:], dtype=dtype, out=self.destination(shape[1:]))[None] if self.rank == self.root else None
             self.stats.update(xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0)
             return out
         is_root = self.rank == self.root
@@ -270,7 +302,7 @@ class DeviceGather:
         t0 = time.perf_counter()
         self.rccl.gather_device(d_send.ptr, d_recv.ptr if is_root else None, nbytes, self.root)
         t1 = time.perf_counter()
-        out = d_recv.download(shape, dtype=dtype) if is_root else None
+        out = d_recv.download(shape, dtype=dtype, out=self.destination(shape)) if is_root else None
         t2 = time.perf_counter()
         if is_root:
             d_recv.free()
@@ -278,7 +310,21 @@ class DeviceGather:
         self.stats.update(xgmi_s=t1 - t0, d2h_s=t2 - t1, gather_bytes=int(nbytes) * (self.world - 1))
         return out
 
-    def run(self, sampler, jobs, order, n_points):
+    def streams_chain(self, first_job):
+        """True where nothing has to be exchanged or post-processed: one rank and the chain itself is the result (C5)."""
+        if os.environ.get("GF_SCAN_NO_STREAMED_CHAIN"):           # A/B: sample, then read back
+            return False
+        return self.rccl is None and self.world == 1 and first_job.post_model is None
+
+    def run(self, sampler, jobs, order, n_points, streamed=None):
+        if streamed is not None:                                  # (nchains, nstored, nwalkers, ndim), read back during the run
+            rows = streamed.reshape(streamed.shape[0], -1, streamed.shape[-1])
+            self.stats = GATHER_STATS
+            self.stats.clear()
+            self.stats.update({"ranks": 1, "slots_per_rank": n_points, "pack_s": 0.0, "xgmi_s": 0.0,
+                               "d2h_s": float(getattr(self, "readback_tail_s", 0.0)), "gather_bytes": 0, "block_bytes": int(rows.nbytes),
+                               "note": "the chain was read back while it was sampled (one rank): d2h_s is what was left after the run's last step"})
+            return [rows[order.index(g)] for g in range(n_points)] if list(order) != list(range(n_points)) else list(rows)
         slots = gdist.slots_per_rank(n_points, self.world)
         first = jobs[order[0]]
         per = sampler.nstored * first.nwalkers                    # samples per grid point
@@ -289,7 +335,8 @@ class DeviceGather:
         if self.rccl is None and self.world == 1 and first.post_model is not None:
             # one rank: no exchange -- rows to the host group by group while the later chains are still post-processed
             t0 = time.perf_counter()
-            rows = sampler.postprocess_rows(models=[jobs[g].post_model for g in order])
+            rows = sampler.postprocess_rows(models=[jobs[g].post_model for g in order],
+                                            out=self.destination((len(order), per, width)))
             self.stats.update(pack_s=0.0, xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0,
                               block_bytes=int(rows.nbytes), note="post-processing and read-back overlap (one rank)")
             return [rows[order.index(g)] for g in range(n_points)] if list(order) != list(range(n_points)) else list(rows)

@@ -224,6 +224,14 @@ int gf_sampler_set_state(gf_sampler* s, const double* pos);
 /* nsteps stretch-move steps, asynchronous; store != 0 appends every thin-th step to the device chain */
 int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store);
 int gf_sampler_sync(gf_sampler* s);
+/* ABI 3.  gf_sampler_run(s, nsteps, thin, 1) with the read-back overlapped: while the GPU works through the run, every finished
+ * block of 16 steps of all chains is copied to the host on a second stream (pinned staging, as gf_memcpy_d2h).  Synchronous: on
+ * return the run is complete and chain [nchains][nstored][nwalkers][ndim], lnprob_chain [nchains][nstored][nwalkers] (may be
+ * NULL) hold the whole stored chain, nstored = gf_sampler_nstored(s) after the call -- size them for
+ * nstored_before + ceil(nsteps / thin).  Replaces run + sync + gf_sampler_get_chain where `sampler.chain` is read after
+ * `sampler.run_mcmc` (golemflavor/mcmc.py:41-43).  *readback_tail_s (may be NULL): seconds from the end of the run on the GPU to the
+ * end of the last copy, i.e. the part of the read-back that was not hidden behind the run. */
+int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chain, double* lnprob_chain, double* readback_tail_s);
 /* clears the stored chain and the acceptance counters, keeps the walkers (mcmc.py:36 sampler.reset()) */
 int gf_sampler_reset(gf_sampler* s);
 int64_t gf_sampler_nstored(const gf_sampler* s);

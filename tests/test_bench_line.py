@@ -102,9 +102,13 @@ class _FakeBuf:
         self.ptr = self.arr                                       # what the product passes on as the "device pointer"
         self.nbytes = nbytes
 
-    def download(self, shape, dtype=np.float64):
+    def download(self, shape, dtype=np.float64, out=None):
         n = int(np.prod(shape))
-        return self.arr[:n].reshape(shape).copy()
+        if out is None:
+            return self.arr[:n].reshape(shape).copy()
+        assert out.shape == tuple(shape)
+        out[...] = self.arr[:n].reshape(shape)
+        return out
 
     def free(self):
         self.arr = None
@@ -172,6 +176,9 @@ def test_device_gather_packing_and_indexing_with_a_fake_rccl(n_points, world, wi
             order = gdist.shard(n_points, rank, world)
             jobs = {g: _Job(nw, ndim, object() if with_rows else None) for g in order}
             g = scan.DeviceGather(_FakeRccl(rank, world, shared, barrier), rank, world, _FakeModel())
+            if n_points % 2:                                       # with and without the result array allocated ahead of the run
+                g.prepare(jobs[order[0]], len(order), n_points, nstored)
+                assert (g._dest is not None) == (rank == 0)        # only the root receives anything
             results[rank] = g.run(_FakeSampler(order, nstored, nw, ndim, with_rows), jobs, order, n_points)
             stats[rank] = dict(g.stats)
         except Exception as exc:           # noqa: BLE001

@@ -167,7 +167,9 @@ def test_reference_length_scan_on_one_gpu(config):
     assert rec["ranks"] == 1 and rec["grid_points"] == npts and rec["burnin"] == 200 and rec["nsteps"] == 1000
     assert rec["chain_bytes_to_host"] == npts * nw * 1000 * width * 8
     assert rec["finite_fraction"] > (0.6 if config == "C4" else 0.999)      # C4's top scales sit in the failing region (NaN rows)
-    assert rec["sampling_s"] > 0 and rec["d2h_s"] > 0 and rec["seconds"] < 60.0
+    assert rec["sampling_s"] > 0 and rec["d2h_s"] >= 0 and rec["seconds"] < 60.0
+    if config == "C4":
+        assert rec["d2h_s"] > 0                                   # C5's chain is read back during the run: what is left is a tail
     assert rec["evals_per_s"] > 1e8
 
 

@@ -162,3 +162,51 @@ def test_large_reads_come_back_through_the_pinned_ring_intact():
             assert np.array_equal(back[3:].view(np.int64), src.view(np.int64)), nbytes
             d.free()
             _lib.device_trim(0)                                  # frees the pinned slots too: the next large read allocates them again
+
+
+@pytest.mark.parametrize("case", ["sm_one_workgroup", "sm_grid", "sm_grid_through_the_ring", "bsm_stacked"])
+def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden):
+    """gf_sampler_run_to_host copies every finished block of steps to the host while the run goes on.  The result must be,
+    bit for bit, what run_mcmc followed by the chain's read-back gives for the same seed: one-workgroup sampler (a single
+    mark), the grid sampler (graph replays of 16 steps + an eager tail), stacked BSM chains with the settle step; with a
+    stored prefix from an earlier run, with thinning, with the lnprob chain."""
+    from golemflavor_amd import mcmc as mcmc_utils
+    rng = np.random.default_rng(9)
+    if case == "bsm_stacked":
+        asimov, ps = Cf.fr_paramsets(6, fr_utils.fr_to_angles((1, 1, 1)))
+        fs = []
+        for tex, x in ((Texture.OET, 0.2), (Texture.OUT, 0.7), (Texture.OEU, 0.5)):
+            args = argparse.Namespace(source_ratio=np.array([x, 1 - x, 0.0]), dimension=6, texture=tex, binning=BIN_EDGES)
+            fs.append(llh_utils.bsm_ln_prob(args, asimov, ps, smearing=0.02, on_nonunitary="-inf"))
+        nw, nd, nch = 128, 12, 3
+        box = np.array(ps.seeds, dtype=float)
+        p0 = rng.uniform(box[:, 0], box[:, 1], size=(nch, nw, nd))
+        p0[:, :, 11] = rng.uniform(-40, -33, size=(nch, nw))          # up into OEU's failing region: proposals get parked
+        make = lambda: mcmc_utils.DeviceEnsembleSampler(nw, nd, fs, seed=4)
+    else:
+        asimov, ps = Cf.notebook_paramsets(golden["g6_asimov_angles"])
+        f = llh_utils.notebook_ln_prob(asimov, ps)
+        fs = [f]
+        # (blocks of 16 steps below 16 MB are plain strided copies; 32 chains of 4096 walkers make 100 MB blocks: the pinned ring)
+        nw, nd, nch = {"sm_one_workgroup": (100, 6, 5), "sm_grid": (4096, 6, 2), "sm_grid_through_the_ring": (4096, 6, 32)}[case]
+        box = np.array(ps.seeds, dtype=float)
+        p0 = rng.uniform(box[:, 0], box[:, 1], size=(nch, nw, nd))
+        make = lambda: mcmc_utils.DeviceEnsembleSampler(nw, nd, f, nchains=nch, seed=4)
+    for thin, first, second in ((1, 0, 75), (1, 40, 53), (3, 20, 100)):
+        a, b = make(), make()
+        for smp in (a, b):
+            smp.on_nonunitary = "-inf"
+            smp.run_mcmc(p0, 30, storechain=False)
+            smp.reset()
+            if first:
+                smp.run_mcmc(None, first, thin=thin)                 # a stored prefix
+        a.run_mcmc(None, second, thin=thin)
+        want, want_lnp, _ = a._fetch(chain=True, lnprob=True)
+        got, got_lnp = b.run_mcmc_to_host(None, second, thin=thin, lnprob=True)
+        assert got.shape == want.shape == (nch, (first + thin - 1) // thin + (second + thin - 1) // thin, nw, nd)
+        assert np.array_equal(got, want) and np.array_equal(got_lnp, want_lnp), (case, thin, first)
+        assert np.array_equal(b.state[0], a.state[0]) and a.nonunitary_proposals == b.nonunitary_proposals
+        assert np.array_equal(b.run_mcmc_to_host(None, 5, thin=thin)[:, :got.shape[1]], got)        # and the chain goes on
+        a.close(); b.close()
+    for f in fs:
+        f.close()
