@@ -8,7 +8,7 @@ from bench import notebook_descriptor, synth_theta
 from golemflavor_amd.model import Model
 ps, bf, desc = notebook_descriptor()
 with Model(desc) as m:
-    for n in (50, 100, 512, 2048, 4096, 65536, 1 << 20, 1 << 22):
+    for n in (50, 100, 512, 2048, 4096, 65536, 1 << 20, 1 << 21, 1 << 22, 1 << 24):
         th = synth_theta(ps, n, 1)
         for _ in range(3):
             m.lnprob(th, want_status=False)
