@@ -1057,12 +1057,17 @@ int gf_sampler_get_chain(gf_sampler* s, double* chain, double* lnprob_chain, uin
     if (s->nstored > 0) {
         // one strided copy per array: row = chain (stored prefix), device pitch = capacity stride
         const size_t row = sizeof(double) * per * s->ndim, lrow = sizeof(double) * per;
-        if (chain)
-            GFS_HIP(hipMemcpy2DAsync(chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored, s->nchains,
-                                     hipMemcpyDeviceToHost, st));
-        if (lnprob_chain)
-            GFS_HIP(hipMemcpy2DAsync(lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap, lrow * s->nstored,
-                                     s->nchains, hipMemcpyDeviceToHost, st));
+        // (gf_internal_d2h_2d: a plain strided copy below 16 MB, the pinned ring + host copy pool from there on)
+        if (chain) {
+            const int rc = gf_internal_d2h_2d(device, stream, chain, row * s->nstored, s->d_chain, row * s->nstore_cap, row * s->nstored,
+                                              (size_t)s->nchains);
+            if (rc != GF_OK) return rc;
+        }
+        if (lnprob_chain) {
+            const int rc = gf_internal_d2h_2d(device, stream, lnprob_chain, lrow * s->nstored, s->d_lnp_chain, lrow * s->nstore_cap,
+                                              lrow * s->nstored, (size_t)s->nchains);
+            if (rc != GF_OK) return rc;
+        }
     }
     if (naccepted)
         GFS_HIP(hipMemcpyAsync(naccepted, s->d_naccept, sizeof(uint32_t) * (size_t)s->nchains * per, hipMemcpyDeviceToHost, st));

@@ -366,8 +366,8 @@ class DeviceEnsembleSampler:
         """Only what is asked for crosses PCIe (the C entry point skips NULL arrays)."""
         from .model import empty_for_download
         ns = int(self._L.gf_sampler_nstored(self._h))
-        c = empty_for_download((self.nchains, ns, self.k, self.dim)) if chain else None
-        lnp = empty_for_download((self.nchains, ns, self.k)) if lnprob else None
+        c = empty_for_download((self.nchains, ns, self.k, self.dim), copier_maps_pages=True) if chain else None
+        lnp = empty_for_download((self.nchains, ns, self.k), copier_maps_pages=True) if lnprob else None
         nacc = np.empty((self.nchains, self.k), dtype=np.uint32) if naccepted else None
         self._lib.check(self._L.gf_sampler_get_chain(
             self._h, c.ctypes.data_as(self._lib._dp) if chain else None, lnp.ctypes.data_as(self._lib._dp) if lnprob else None,
