@@ -218,7 +218,8 @@ __device__ __forceinline__ void grp_walker_terms(const Grp& g, const GfCommon& c
 
 // One energy bin (gf_x87.hpp bin_residual + cardano_residual, fr.py:170-237 and 489-494) on the group's three lanes; every
 // lane returns the same residual.
-__device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3], const cx87 hn[3], double pre, double epow)
+__device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3], const cx87 hn[3], double pre, double epow,
+                                                   long long* tick = nullptr)      // tick: diagnostics (k_uni_debug_group)
 {
     const int r = g.r;
     cx87* M = g.M;
@@ -253,6 +254,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
 #pragma unroll
     for (int j = 0; j < 3; ++j) M[3 * r + j] = c_add(c_scale(xp, hs[j]), c_scale(xe, hn[j]));      // fr.py:386, 394-395
     grp_sync();
+    if (tick) tick[0] = clock64();
     // cardano_residual
     const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0);
     const cx87 tr = c_add(c_add(M[0], M[4]), M[8]);
@@ -281,6 +283,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     }
     grp_sync();
     const cx87 h10h02 = g.ex[0], h21h10 = g.ex[1], h12h20 = g.ex[2];
+    if (tick) tick[1] = clock64();
     const cx87 a = c_neg(tr);                                                           // fr.py:204
     const cx87 b = c_scale(GFX_X87_HALF, c_sub(c_mul(tr, tr), tr2));                    // fr.py:205
     const cx87 c = c_neg(det);                                                          // fr.py:206
@@ -289,6 +292,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     const cx87 R = c_scale(GFX_X87_54TH,
                            c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
     const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
+    if (tick) tick[2] = clock64();
     const cx87 sq = c_sqrt_pos(Q);
     const cx87 m2sq = c_scale(x_neg(two), sq);
     const cx87 third_a = c_scale(GFX_X87_THIRD, a);
@@ -299,6 +303,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     if (r == 1) are = x_sub(theta.re, twopi);
     if (r == 2) are = x_add(theta.re, twopi);
     const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(are, theta.im), three))), third_a);
+    if (tick) tick[3] = clock64();
     // eigenvector r (fr.py:216-236)
     const cx87 A = c_sub(c_mul(M[5], c_sub(M[0], E)), h10h02);
     const cx87 B = c_sub(c_mul(M[6], c_sub(M[4], E)), h21h10);
@@ -309,6 +314,7 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     const cx87 x0 = c_div_real(c_mul(c_conj(B), C), N);                                 // fr.py:232-236
     const cx87 x1 = c_div_real(AC, N);
     const cx87 x2 = c_div_real(AB, N);
+    if (tick) tick[4] = clock64();
     grp_sync();                                                                         // every lane is done with H
     M[0 + r] = x0; M[3 + r] = x1; M[6 + r] = x2;                                        // column r of X
     grp_sync();
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(64) void k_uni_debug_serial(const GfCommon* __restr
 __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                                const double* __restrict__ theta, int layout, int64_t n,
                                                                const int64_t* __restrict__ walkers, const int32_t* __restrict__ bins, int64_t npairs,
-                                                               double* __restrict__ out)
+                                                               double* __restrict__ out, int timing)
 {
     __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -623,9 +629,24 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* _
     const int64_t groups = (int64_t)gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE;
     for (int64_t t = ((int64_t)blockIdx.x * (UNI_BLOCK / 64) + wave) * GRP_PER_WAVE + grp; t < npairs; t += groups) {
         cx87 hs[3], hn[3];
+        const long long c0 = clock64();
         grp_walker_terms(g, *cp, *tbp, theta, layout, n, walkers[t], hs, hn);
-        const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[bins[t]], tbp->epow[bins[t]]);
-        if (g.r == 0) out[t] = res;
+        const long long c1 = clock64();
+        long long tick[5] = {0, 0, 0, 0, 0};
+        const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[bins[t]], tbp->epow[bins[t]], timing >= 3 ? tick : nullptr);
+        const long long c2 = clock64();
+        // timing (tools/arb_latency_probe.py): shader-clock cycles of the walker's terms / of the bin / of the bin's sections
+        // instead of the residual
+        double o = res;
+        if (timing == 1) o = (double)(c1 - c0);
+        if (timing == 2) o = (double)(c2 - c1);
+        if (timing == 3) o = (double)(tick[0] - c1);        // scaling + H
+        if (timing == 4) o = (double)(tick[1] - tick[0]);   // tr, tr H^2, det, shared products
+        if (timing == 5) o = (double)(tick[2] - tick[1]);   // b, Q, R, sqrt(Q^3), division, arccos
+        if (timing == 6) o = (double)(tick[3] - tick[2]);   // sqrt Q, cos, eigenvalue
+        if (timing == 7) o = (double)(tick[4] - tick[3]);   // eigenvector
+        if (timing == 8) o = (double)(c2 - tick[4]);        // |X X^+|, sums
+        if (g.r == 0) out[t] = o;
     }
 }
 
@@ -655,7 +676,7 @@ hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, con
                                const int32_t* bins, int64_t npairs, int which, double* out, hipStream_t s)
 {
     if (which == 0) hipLaunchKernelGGL(k_uni_debug_serial, dim3(512), dim3(64), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out);
-    else hipLaunchKernelGGL(k_uni_debug_group, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out);
+    else hipLaunchKernelGGL(k_uni_debug_group, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out, which - 1);
     return hipGetLastError();
 }
 

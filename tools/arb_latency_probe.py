@@ -26,3 +26,16 @@ with Model(compile_model(ps, "BSM_GAUSS", texture=Texture.OEU, **kw)) as m:
                 L.gf_internal_uni_residuals(m._h, d_th.ptr, 0, n, d_w.ptr, d_b.ptr, npairs, which, d_o.ptr)
             dt = (time.perf_counter() - t0) / 5
             print("pairs %7d (setup + 1 bin each, 3 lanes per pair, grid 512 x 128): %.1f us per call" % (npairs, 1e6 * dt))
+
+    # where one (walker, bin)'s chain goes: shader-clock cycles of the walker's terms (angles_to_u of the sampled mixing angles,
+    # the two sandwiches, 10^x) and of one bin (cardano_eqn + test_unitarity), a single pair alone on the GPU and a full grid
+    for npairs in (1, 21504):
+        w = np.arange(npairs, dtype=np.int64) % n
+        b = (np.arange(npairs) % 20).astype(np.int32)
+        d_w, d_b, d_o = m.alloc(w.nbytes).upload(w), m.alloc(b.nbytes).upload(b), m.alloc(8 * npairs)
+        for which, label in ((2, "walker terms"), (3, "one bin"), (4, " bin: scaling + H"), (5, " bin: tr, tr H^2, det"), (6, " bin: Q, R, sqrt, /, arccos"),
+                             (7, " bin: sqrt Q, cos, eigenvalue"), (8, " bin: eigenvector"), (9, " bin: |X X^+|, sums")):
+            L.gf_internal_uni_residuals(m._h, d_th.ptr, 0, n, d_w.ptr, d_b.ptr, npairs, which, d_o.ptr)
+            L.gf_internal_uni_residuals(m._h, d_th.ptr, 0, n, d_w.ptr, d_b.ptr, npairs, which, d_o.ptr)
+            cyc = d_o.download((npairs,))
+            print("pairs %6d  %-30s: median %.0f cycles (min %.0f, max %.0f) = %.1f us at 2.4 GHz" % (npairs, label, np.median(cyc), cyc.min(), cyc.max(), np.median(cyc) / 2400.0))
