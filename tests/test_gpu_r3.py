@@ -164,7 +164,7 @@ def test_large_reads_come_back_through_the_pinned_ring_intact():
             _lib.device_trim(0)                                  # frees the pinned slots too: the next large read allocates them again
 
 
-@pytest.mark.parametrize("case", ["sm_one_workgroup", "sm_grid", "sm_grid_through_the_ring", "bsm_stacked"])
+@pytest.mark.parametrize("case", ["sm_one_workgroup", "sm_grid", "sm_grid_through_the_ring", "sm_grid_one_wide_chain", "bsm_stacked"])
 def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden):
     """gf_sampler_run_to_host copies every finished block of steps to the host while the run goes on.  The result must be,
     bit for bit, what run_mcmc followed by the chain's read-back gives for the same seed: one-workgroup sampler (a single
@@ -188,7 +188,9 @@ def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden):
         f = llh_utils.notebook_ln_prob(asimov, ps)
         fs = [f]
         # (blocks of 16 steps below 16 MB are plain strided copies; 32 chains of 4096 walkers make 100 MB blocks: the pinned ring)
-        nw, nd, nch = {"sm_one_workgroup": (100, 6, 5), "sm_grid": (4096, 6, 2), "sm_grid_through_the_ring": (4096, 6, 32)}[case]
+        # one chain of 65 536 walkers: a block of 16 steps is ONE row of 50 MB, wider than a 16 MB slot -> the row-by-row fallback
+        nw, nd, nch = {"sm_one_workgroup": (100, 6, 5), "sm_grid": (4096, 6, 2), "sm_grid_through_the_ring": (4096, 6, 32),
+                       "sm_grid_one_wide_chain": (65536, 6, 1)}[case]
         box = np.array(ps.seeds, dtype=float)
         p0 = rng.uniform(box[:, 0], box[:, 1], size=(nch, nw, nd))
         make = lambda: mcmc_utils.DeviceEnsembleSampler(nw, nd, f, nchains=nch, seed=4)
@@ -207,6 +209,7 @@ def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden):
         assert np.array_equal(got, want) and np.array_equal(got_lnp, want_lnp), (case, thin, first)
         assert np.array_equal(b.state[0], a.state[0]) and a.nonunitary_proposals == b.nonunitary_proposals
         assert np.array_equal(b.run_mcmc_to_host(None, 5, thin=thin)[:, :got.shape[1]], got)        # and the chain goes on
+        assert np.array_equal(b.run_mcmc_to_host(None, 0), b._fetch(chain=True)[0])                 # nothing new: the stored chain
         a.close(); b.close()
     for f in fs:
         f.close()
