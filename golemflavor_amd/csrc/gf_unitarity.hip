@@ -285,15 +285,21 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     const cx87 h10h02 = g.ex[0], h21h10 = g.ex[1], h12h20 = g.ex[2];
     if (tick) tick[1] = clock64();
     const cx87 a = c_neg(tr);                                                           // fr.py:204
-    const cx87 b = c_scale(GFX_X87_HALF, c_sub(c_mul(tr, tr), tr2));                    // fr.py:205
+    const cx87 a2 = c_mul(tr, tr);                                                      // = a a, bit for bit: (-x)(-y) is x y
+    const cx87 b = c_scale(GFX_X87_HALF, c_sub(a2, tr2));                               // fr.py:205
     const cx87 c = c_neg(det);                                                          // fr.py:206
-    const cx87 a2 = c_mul(a, a);
     const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
     const cx87 R = c_scale(GFX_X87_54TH,
                            c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
-    const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
+    // the two complex square roots of the bin, sqrt(Q^3) (fr.py:210) and sqrt(Q) (fr.py:212-214), in ONE pass: lanes 0 and 1 take
+    // the first, lane 2 the second, and they meet in the exchange slot
+    const cx87 Q3 = c_mul(Q, c_mul(Q, Q));
+    g.ex[r] = c_sqrt_pos(r == 2 ? Q : Q3);
+    grp_sync();
+    const cx87 sqQ3 = g.ex[0], sq = g.ex[2];
+    grp_sync();
+    const cx87 theta = c_acos_near_real(c_div(R, sqQ3));                                // fr.py:210
     if (tick) tick[2] = clock64();
-    const cx87 sq = c_sqrt_pos(Q);
     const cx87 m2sq = c_scale(x_neg(two), sq);
     const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
@@ -311,9 +317,12 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     const cx87 AB = c_mul(A, B), AC = c_mul(A, C), BC = c_mul(B, C);
     const x87 ab = c_abs(AB), ac = c_abs(AC), bc = c_abs(BC);
     const x87 N = x_sqrt(x_add(x_add(x_mul(ab, ab), x_mul(ac, ac)), x_mul(bc, bc)));   // fr.py:228-230
-    const cx87 x0 = c_div_real(c_mul(c_conj(B), C), N);                                 // fr.py:232-236
-    const cx87 x1 = c_div_real(AC, N);
-    const cx87 x2 = c_div_real(AB, N);
+    // fr.py:232-236: complex / real is x * (1 / d) in numpy (c_div_real): the reciprocal once for the three components
+    const x87 rn = x_div(x_from(1.0), N);
+    const cx87 cbc = c_mul(c_conj(B), C);
+    const cx87 x0 = c_make(x_mul(cbc.re, rn), x_mul(cbc.im, rn));
+    const cx87 x1 = c_make(x_mul(AC.re, rn), x_mul(AC.im, rn));
+    const cx87 x2 = c_make(x_mul(AB.re, rn), x_mul(AB.im, rn));
     if (tick) tick[4] = clock64();
     grp_sync();                                                                         // every lane is done with H
     M[0 + r] = x0; M[3 + r] = x1; M[6 + r] = x2;                                        // column r of X

@@ -284,16 +284,37 @@ GFX_HD GFX_BIG void dd_sincos(dd x, dd& sn, dd& cs)
     cs = q == 0 ? c : (q == 1 ? ns : (q == 2 ? nc : s));
 }
 
-// asin for |t| <= ~0.75: one Newton step on sin from the fp64 value (error e -> e^2 tan / 2)
+// sin x for 0 <= |x| <= 0.81 without argument reduction (dd_asin_small: x = asin of at most 0.72): the odd series alone, half of
+// dd_sincos's work and no quadrant to branch on.  x^31 / 31! < 2^-111 x at 0.81; the orders from x^17 on are below 2^-53 of the
+// leading term and are summed in fp64 (rounding errors below 2^-106).
+GFX_HD GFX_BIG dd dd_sin_small(dd x)
+{
+    static const ddc F[30] = {GFX_INV_FACT_TABLE};
+    const dd t = dd_mul(x, x);
+    double ts = F[29].hi;
+    GFX_ROLLED
+    for (int k = 13; k >= 8; --k) ts = x_fma(ts, t.hi, (k & 1) ? -F[2 * k + 1].hi : F[2 * k + 1].hi);
+    dd v = dd_from(ts);
+    GFX_ROLLED
+    for (int k = 7; k >= 0; --k) {
+        const ddc fs = F[2 * k + 1];
+        const dd sk = {(k & 1) ? -fs.hi : fs.hi, (k & 1) ? -fs.lo : fs.lo};
+        v = dd_add(dd_mul(v, t), sk);
+    }
+    return dd_mul(v, x);
+}
+
+// asin for |t| <= ~0.75: one Newton step on sin from the fp64 value (error e -> e^2 tan / 2).  The step needs sin(th0) to full
+// double-double accuracy but cos(th0) only as the divisor of a correction of relative size 1e-16: fp64, from the sine.
 GFX_HD inline dd dd_asin_small(dd t)
 {
     if (t.hi == 0.0) return t;
     const double th0 = asin(t.hi);
-    dd s, c;
-    dd_sincos(dd_from(th0), s, c);
+    const dd s = dd_sin_small(dd_from(th0));                          // th0 <= asin(0.75) = 0.85 at the very most
+    const double c = sqrt(x_fma(-s.hi, s.hi, 1.0));                   // |s| <= 0.75: no cancellation to speak of
     const dd d = dd_sub(s, t);
     dd r;
-    two_sum(th0, -(d.hi / c.hi), r.hi, r.lo);
+    two_sum(th0, -(d.hi / c), r.hi, r.lo);
     return r;
 }
 
