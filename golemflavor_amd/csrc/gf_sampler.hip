@@ -796,6 +796,8 @@ void mark_block(gf_sampler* s, hipStream_t st, int64_t nstored)
         delete[] s->mark_events; delete[] s->mark_nstored;
         s->mark_events = ev; s->mark_nstored = ns; s->mark_cap = cap;
     }
+    static const bool trace = std::getenv("GF_TRACE_MARKS") != nullptr;
+    if (trace) std::fprintf(stderr, "mark %d at %lld stored steps\n", s->nmarks, (long long)nstored);
     hipEvent_t& e = s->mark_events[s->nmarks];
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); return; }
     if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -987,7 +989,7 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
     if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
     GFS_HIP(hipSetDevice(device));
-    s->marking = true;
+    s->marking = gf_internal_env("GF_RUN_TO_HOST_NO_MARKS", 0) == nullptr;      // diagnostics: no marks = one copy after the run
     s->nmarks = 0;
     int rc = gf_sampler_run(s, nsteps, thin, 1);
     s->marking = false;

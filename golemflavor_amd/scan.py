@@ -273,6 +273,8 @@ class DeviceGather:
         pages mapped in the background while the GPU samples (model.Prefaulted).  Only where this rank receives anything."""
         per = nsteps * first_job.nwalkers
         width = first_job.ndim if first_job.post_model is None else 3 + first_job.ndim
+        if os.environ.get("GF_SCAN_NO_PREFAULT"):                 # A/B: the callee allocates when it needs the array
+            return
         if self.streams_chain(first_job):
             shape = (n_local, nsteps, first_job.nwalkers, first_job.ndim)
         elif self.rccl is not None and self.rank == self.root:
