@@ -1417,10 +1417,12 @@ int gf_host_prepare(void* buf, size_t bytes)
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
     if (bytes / min_per_thread < nt) nt = bytes / min_per_thread ? bytes / min_per_thread : 1;
+    // an atomic OR with zero: a write access (the page is mapped writable, not to the shared zero page) that leaves the content
+    // alone and cannot lose a byte another thread stores at the same moment -- so a buffer may be prepared WHILE a copy fills it
     auto touch = [=](size_t lo, size_t hi) {
-        volatile char* p = static_cast<volatile char*>(buf);
-        for (size_t o = lo; o < hi; o += page) p[o] = 0;
-        if (hi > lo) p[hi - 1] = 0;
+        char* p = static_cast<char*>(buf);
+        for (size_t o = lo; o < hi; o += page) (void)__atomic_fetch_or(p + o, (char)0, __ATOMIC_RELAXED);
+        if (hi > lo) (void)__atomic_fetch_or(p + hi - 1, (char)0, __ATOMIC_RELAXED);
     };
     if (nt == 1) { touch(0, bytes); return GF_OK; }
     std::vector<std::thread> th;

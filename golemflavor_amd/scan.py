@@ -205,6 +205,7 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         if gather is not None and gather.streams_chain(first):
             # one rank, the chain is the result: its blocks of steps cross PCIe while the later ones are sampled
             streamed = sampler.run_mcmc_to_host(None, nsteps, out=gather.destination((len(order), nsteps, first.nwalkers, first.ndim)))
+            gather.finish_destination()
             gather.readback_tail_s = sampler.readback_tail_s
         else:
             sampler.run_mcmc(None, nsteps)
@@ -286,17 +287,27 @@ class DeviceGather:
         self._dest = Prefaulted(shape)
 
     def destination(self, shape):
-        """The prepared array if it has this shape (else None: the callee allocates)."""
+        """The prepared array if it has this shape (else None: the callee allocates).  Its pages may still be being mapped: the
+        copy that fills it may start at once (model.Prefaulted); `finish_destination` waits for the mapping thread."""
         d, self._dest = self._dest, None
         if d is None:
             return None
-        a = d.get()
-        return a if a.shape == tuple(shape) else None
+        if d.array.shape != tuple(shape):
+            d.finish()
+            return None
+        self._mapping = d
+        return d.array
+
+    def finish_destination(self):
+        d, self._mapping = getattr(self, "_mapping", None), None
+        if d is not None:
+            d.finish()
 
     def _exchange(self, d_send, nbytes, shape, dtype):
         if self.rccl is None:
             t0 = time.perf_counter()
             out = d_send.download(shape[1:], dtype=dtype, out=self.destination(shape[1:]))[None] if self.rank == self.root else None
+            self.finish_destination()
             self.stats.update(xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0)
             return out
         is_root = self.rank == self.root
@@ -305,6 +316,7 @@ class DeviceGather:
         self.rccl.gather_device(d_send.ptr, d_recv.ptr if is_root else None, nbytes, self.root)
         t1 = time.perf_counter()
         out = d_recv.download(shape, dtype=dtype, out=self.destination(shape)) if is_root else None
+        self.finish_destination()
         t2 = time.perf_counter()
         if is_root:
             d_recv.free()
@@ -339,6 +351,7 @@ class DeviceGather:
             t0 = time.perf_counter()
             rows = sampler.postprocess_rows(models=[jobs[g].post_model for g in order],
                                             out=self.destination((len(order), per, width)))
+            self.finish_destination()
             self.stats.update(pack_s=0.0, xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0,
                               block_bytes=int(rows.nbytes), note="post-processing and read-back overlap (one rank)")
             return [rows[order.index(g)] for g in range(n_points)] if list(order) != list(range(n_points)) else list(rows)

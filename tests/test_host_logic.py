@@ -397,3 +397,22 @@ def test_scan_point_descriptors_are_the_compiled_ones():
         scan._patched(post, texture=Texture.NONE)
     with pytest.raises(KeyError):
         scan._patched(post, dimension=4)
+
+
+def test_host_prepare_keeps_the_content_and_tolerates_a_concurrent_writer():
+    """gf_host_prepare maps the pages of a result buffer from several threads with an atomic OR of zero per page: what the
+    buffer holds stays, also while another thread is filling it (a scan maps its result array during the run that fills it)."""
+    import threading
+    L = _lib.lib()
+    n = 64 << 20
+    a = np.arange(n // 8, dtype=np.float64)
+    assert L.gf_host_prepare(a.ctypes.data_as(C.c_void_p), a.nbytes) == _lib.GF_OK
+    assert np.array_equal(a, np.arange(n // 8, dtype=np.float64))
+    b = np.empty(n // 8)
+    src = np.random.default_rng(0).random(n // 8)
+    t = threading.Thread(target=lambda: L.gf_host_prepare(b.ctypes.data_as(C.c_void_p), b.nbytes))
+    t.start()
+    b[:] = src                                                     # races with the page touches
+    t.join()
+    assert np.array_equal(b, src)
+    assert L.gf_host_prepare(None, 0) == _lib.GF_OK
