@@ -478,6 +478,17 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
 // the end of a walker -- one bin failed, or all of them passed -- lane 0 of the group completes that walker's half-step exactly
 // as the half-step kernel does for the proposals it settles itself: a proposal the reference would have raised on is rejected
 // and counted, any other goes through the accept test ln(z^(ndim-1) / u) > lnp(s) - lnp(q); the stored sample is written.
+#ifdef GF_SETTLE_TIMING
+// diagnostics build (tools/settle_timing.py): where a settle launch's time goes, on the 100 MHz wall clock all CUs share --
+// [0] earliest kernel entry, [1] latest end of a walker's terms, [2] latest end of a bin, [3] latest completed walker, [4] latest block exit,
+// [5] launches with work; all accumulated as (value - entry) sums over launches in [6..9]
+__device__ unsigned long long g_settle_t[12];
+__device__ unsigned long long g_settle_c[4];      // shader-clock counts: [0] sum over launches of the longest (terms), [1] of the longest (terms + bin)
+__device__ unsigned long long g_settle_cmax[4];
+#define GF_ST_MARK(i) do { if (g.r == 0) { atomicMax(&g_settle_t[i], (unsigned long long)wall_clock64()); if (i <= 2) atomicMax(&g_settle_cmax[i], (unsigned long long)(clock64() - c_entry)); } } while (0)
+#else
+#define GF_ST_MARK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(const GfSettleArgs s)
 {
     __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
@@ -487,6 +498,10 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     // re-arm (count and head are zero already).  No block changes the queue before EVERY block has read the count: the re-arming
     // below is done by the last block to arrive, so all blocks take the same branch here.
     if (count == 0u && uq->overflow == 0u) return;
+#ifdef GF_SETTLE_TIMING
+    if (threadIdx.x == 0) atomicMin(&g_settle_t[0], (unsigned long long)wall_clock64());
+    const long long c_entry = clock64();
+#endif
     {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / GRP;
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     int chain = 0;
     unsigned int parts = 1;
     bool exhausted = !active, failed = false, mine = false;             // mine: this group holds a part whose end it must report
+    unsigned int warm = 0u;
     for (;;) {
         const bool need = !exhausted && !mine;
         const unsigned long long nb = __ballot(need && g.r == 0);
@@ -538,7 +554,20 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                         chain = (int)(t / nhalf);
                         const GfCommon& c = s.commons[s.multi ? chain : 0];
                         const GfBsm& tb = *(s.multi ? s.tbs[chain] : s.tb);
+                        // The chain's constants sit behind per-group pointers: every field the chain reads is a vector load, and
+                        // between the fences of the row exchanges each one is waited for where it is used -- a dozen exposed
+                        // latencies on the one path the whole half-step waits for.  Touch the lines now, back to back; the results
+                        // are only looked at when the kernel ends.
+                        {
+                            const int kb = 63 - __clzll((long long)mask);
+                            const void* lines[12] = {&c.idx_sm[0], &c.idx_mass[0], &c.mass_fixed[0], &c.idx_scale, &c.scale_fixed, &c.idx_mm[0], &tb.texture,
+                                                     &tb.npu_hi[6 * g.r], &tb.npu_lo[6 * g.r], &tb.inv2e[kb], &tb.epow[kb],
+                                                     s.pend_rows + (size_t)t * GF_PEND_STRIDE};
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) warm ^= *static_cast<const volatile unsigned int*>(lines[q]);
+                        }
                         grp_walker_terms(g, c, tb, s.pend_rows, 0, nprop, t, hs, hn, GF_PEND_STRIDE);
+                        GF_ST_MARK(1);
                     }
                 } else {
                     exhausted = true;
@@ -553,6 +582,7 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                 const int k = 63 - __clzll((long long)mask);
                 mask &= ~(1ull << k);
                 const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+                GF_ST_MARK(2);
                 if (!(res < 1e-7)) { failed = true; mask = 0ull; }      // fr.py:493-494: the reference raises
             }
             if (mask == 0ull) {
@@ -587,16 +617,30 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                             for (int d = 0; d < ndim; ++d) dst[d] = accept ? row[d] : pw[d];
                             if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * s.nwalkers + w] = accept ? lnq : lnk;
                         }
+                        GF_ST_MARK(3);
                     }
                 }
             }
         }
     }
+    if (warm == 0x9e3779b9u && s.nchains < 0) s.flags[1] = warm;      // (never: keeps the early loads alive)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
+#ifdef GF_SETTLE_TIMING
+        atomicMax(&g_settle_t[4], (unsigned long long)wall_clock64());
+#endif
         if (atomicAdd(&uq->done, 1u) == gridDim.x - 1) {                // the last block re-arms the queue for the next half-step
+#ifdef GF_SETTLE_TIMING
+            {   // fold this launch into the sums and re-arm the extrema
+                const unsigned long long t0 = g_settle_t[0];
+                for (int i = 1; i <= 4; ++i) { g_settle_t[5 + i] += g_settle_t[i] > t0 ? g_settle_t[i] - t0 : 0ull; g_settle_t[i] = 0ull; }
+                g_settle_t[5] += 1ull; g_settle_t[10] += count;
+                g_settle_c[0] += g_settle_cmax[1]; g_settle_c[1] += g_settle_cmax[2]; g_settle_cmax[1] = g_settle_cmax[2] = 0ull;
+                g_settle_t[0] = ~0ull;
+            }
+#endif
             uq->count = 0;
             uq->done = 0;
             uq->head = 0;
@@ -639,6 +683,7 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* _
     for (int64_t t = ((int64_t)blockIdx.x * (UNI_BLOCK / 64) + wave) * GRP_PER_WAVE + grp; t < npairs; t += groups) {
         cx87 hs[3], hn[3];
         const long long c0 = clock64();
+        const long long w0 = wall_clock64();
         grp_walker_terms(g, *cp, *tbp, theta, layout, n, walkers[t], hs, hn);
         const long long c1 = clock64();
         long long tick[5] = {0, 0, 0, 0, 0};
@@ -655,11 +700,28 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* _
         if (timing == 6) o = (double)(tick[3] - tick[2]);   // sqrt Q, cos, eigenvalue
         if (timing == 7) o = (double)(tick[4] - tick[3]);   // eigenvector
         if (timing == 8) o = (double)(c2 - tick[4]);        // |X X^+|, sums
+        if (timing == 9) o = (double)(c2 - c0) / (10.0 * (double)(wall_clock64() - w0));   // clock64 counts per ns of the 100 MHz wall clock
+        if (timing == 10) o = 10.0 * (double)(wall_clock64() - w0);                         // terms + bin in ns of the wall clock
         if (g.r == 0) out[t] = o;
     }
 }
 
 }  // namespace
+
+#ifdef GF_SETTLE_TIMING
+extern "C" int gf_internal_settle_timing(unsigned long long* out, int reset)
+{
+    unsigned long long h[12];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_settle_t), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 12; ++i) out[i] = h[i];
+    unsigned long long hc[4];
+    if (hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_settle_c), sizeof(hc)) != hipSuccess) return 1;
+    out[12] = hc[0]; out[13] = hc[1];
+    if (reset) { hc[0] = hc[1] = hc[2] = hc[3] = 0ull; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_settle_c), hc, sizeof(hc)); }
+    if (reset) { for (int i = 0; i < 12; ++i) h[i] = 0ull; h[0] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_settle_t), h, sizeof(h)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 // the sampler's settle step; the count is on the device, the groups fetch dynamically: a modest fixed grid (it sits in a captured
 // graph and runs after every half-step, almost always on an empty queue -- where its cost is the launch)
