@@ -39,8 +39,8 @@ class Prefaulted:
         self._t = None
         if self.array.nbytes >= PREPARE_MIN_BYTES:
             L = _lib.lib()
-            ptr, nbytes = self.array.ctypes.data_as(C.c_void_p), self.array.nbytes
-            self._t = threading.Thread(target=lambda: L.gf_host_prepare(ptr, nbytes), daemon=True)
+            # (the closure keeps the array alive for as long as the thread touches it, whatever happens to this object)
+            self._t = threading.Thread(target=lambda a=self.array: L.gf_host_prepare(a.ctypes.data_as(C.c_void_p), a.nbytes), daemon=True)
             self._t.start()
 
     def finish(self):
