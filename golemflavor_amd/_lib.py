@@ -110,6 +110,7 @@ SIGNATURES = {
     "gf_comm_last_error": (C.c_char_p, []),
     "gf_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "gf_host_prepare": (C.c_int, [_vp, C.c_size_t]),
+    "gf_host_prepare_n": (C.c_int, [_vp, C.c_size_t, C.c_int]),
     "gf_sampler_set_stream_ids": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "gf_sampler_get_chain_device": (C.c_int, [_vp, _vp, _vp]),
     "gf_sampler_postprocess_device": (C.c_int, [_vp, C.POINTER(_vp), _vp, _vp]),

@@ -1407,7 +1407,13 @@ int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uin
 // (tools/pcie_probe.*): a D2H into untouched malloc / np.empty memory runs at 11-20 GB/s (page faults inside the copy),
 // into touched pageable memory at 48-56 GB/s -- the rate of pinned memory, whose allocation itself costs 4.7 GB/s;
 // touching 2 GiB takes 17 ms with 8 threads.
-int gf_host_prepare(void* buf, size_t bytes)
+int gf_host_prepare_n(void* buf, size_t bytes, int threads);
+int gf_host_prepare(void* buf, size_t bytes) { return gf_host_prepare_n(buf, bytes, 0); }
+
+// threads <= 0: up to 16 (as many as finish 2 GiB in ~15 ms); a caller that lets the mapping run BESIDE its own work asks for
+// few: sixteen threads taking page faults hold up the main thread's launches and allocations (they share the address space's
+// lock), two do not and still stay ahead of a PCIe copy (profiles/r03/readback.txt)
+int gf_host_prepare_n(void* buf, size_t bytes, int threads)
 {
     if (!buf && bytes) return GF_ERR_INVALID_ARG;
     const size_t page = 4096;
@@ -1416,6 +1422,8 @@ int gf_host_prepare(void* buf, size_t bytes)
     size_t nt = hw ? hw / 2 : 4;
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
+    if (threads > 0) nt = (size_t)(threads > 64 ? 64 : threads);
+    if (const char* e = gf_internal_env("GF_PREPARE_THREADS", 0)) { const long k = std::atol(e); if (k >= 1 && k <= 64) nt = (size_t)k; }   // A/B
     if (bytes / min_per_thread < nt) nt = bytes / min_per_thread ? bytes / min_per_thread : 1;
     // an atomic OR with zero: a write access (the page is mapped writable, not to the shared zero page) that leaves the content
     // alone and cannot lose a byte another thread stores at the same moment -- so a buffer may be prepared WHILE a copy fills it

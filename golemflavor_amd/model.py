@@ -33,14 +33,14 @@ class Prefaulted:
     the content and may overlap the copy that fills the array (an atomic OR with zero per page): `array` can be handed to
     the copy at once; `get()` / `finish()` join the thread."""
 
-    def __init__(self, shape, dtype=np.float64):
+    def __init__(self, shape, dtype=np.float64, threads=0):
         import threading
         self.array = np.empty(shape, dtype=dtype)
         self._t = None
         if self.array.nbytes >= PREPARE_MIN_BYTES:
             L = _lib.lib()
             # (the closure keeps the array alive for as long as the thread touches it, whatever happens to this object)
-            self._t = threading.Thread(target=lambda a=self.array: L.gf_host_prepare(a.ctypes.data_as(C.c_void_p), a.nbytes), daemon=True)
+            self._t = threading.Thread(target=lambda a=self.array: L.gf_host_prepare_n(a.ctypes.data_as(C.c_void_p), a.nbytes, int(threads)), daemon=True)
             self._t.start()
 
     def finish(self):

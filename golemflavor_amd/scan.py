@@ -276,15 +276,19 @@ class DeviceGather:
         width = first_job.ndim if first_job.post_model is None else 3 + first_job.ndim
         if os.environ.get("GF_SCAN_NO_PREFAULT"):                 # A/B: the callee allocates when it needs the array
             return
+        threads = 0
         if self.streams_chain(first_job):
             shape = (n_local, nsteps, first_job.nwalkers, first_job.ndim)
         elif self.rccl is not None and self.rank == self.root:
             shape = (self.world, gdist.slots_per_rank(n_points, self.world), per, width)
+        elif self.rccl is None and self.world == 1:
+            # one rank with post-processing (C4): the sampling takes 7-20 ms and is followed by allocations and many launches, all
+            # of which sixteen page-faulting threads hold up (measured: a net loss); TWO threads run ahead of the read-back without
+            # getting in the way: c4_scan 0.084 -> 0.066 s (profiles/r03/readback.txt)
+            shape, threads = (n_local, per, width), 2
         else:
-            # (one rank with post-processing, C4: the sampling takes 7-20 ms, less than mapping the pages does, and the page
-            # faults of 16 threads hold up the main thread's launches and allocations -- measured slower, profiles/r03/readback.txt)
             return
-        self._dest = Prefaulted(shape)
+        self._dest = Prefaulted(shape, threads=threads)
 
     def destination(self, shape):
         """The prepared array if it has this shape (else None: the callee allocates).  Its pages may still be being mapped: the

@@ -194,6 +194,9 @@ int gf_model_sync(gf_model* m);
  * large device-to-host copy (gf_sampler_get_chain: sampler.chain of golemflavor/mcmc.py:43) runs at PCIe speed instead of
  * page-fault speed.  (gf_memcpy_d2h and gf_sampler_postprocess_rows do not need it: their staging threads map the pages.) */
 int gf_host_prepare(void* buf, size_t bytes);
+/* ABI 3.  The same with the number of threads chosen by the caller (<= 0: the default, up to 16): few threads when the mapping is to
+ * run beside the caller's own launches and allocations, which many page-faulting threads hold up. */
+int gf_host_prepare_n(void* buf, size_t bytes, int threads);
 
 /* HIP events on the model's stream (what bench.py times the kernel with) */
 int gf_event_create(void** ev);
