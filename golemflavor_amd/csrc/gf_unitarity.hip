@@ -356,6 +356,268 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     return res;
 }
 
+// ---- nine lanes per walker ---------------------------------------------------------------------------------------------
+// The same chain once more, for the one place where a walker's LATENCY is what the caller waits for (the device sampler's
+// settle step: a half-step stands still until the slowest parked proposal has its verdict).  Lane l = 3 r + c of a group owns
+// ENTRY (r, c) of every 3x3 matrix: the four angle functions, the eighteen entries of the two sandwiches, the nine products
+// of tr H^2, the nine of the determinant and the eigenvectors' shared terms, the three components of each eigenvector and
+// the six entries of |X X^+| are each one lane's work instead of a row's; rows / columns meet in the group's LDS slot.
+// Still every operation is the serial chain's, on the same operands in the same order: the residual is the serial chain's bit
+// for bit (tests/test_gpu_unitarity_r3.py).  Seven groups per wave; not used for the bulk path, where the three-lane form
+// wastes fewer lanes on the scalar part.
+constexpr int G9 = 9;
+constexpr int G9_PER_WAVE = 64 / G9;                 // 7 (lane 63 idles)
+constexpr int G9_DOUBLES = 4 * 36 + 50;              // four 3x3 complex arrays + a small exchange area; 1552 B, LDS bank step 194
+struct Grp9 {
+    cx87 *A0, *A1, *A2, *A3;                         // [9] each
+    double* sm;                                      // [48] small exchanges
+    int r, c, l;
+};
+
+// entry (r, c) of angles_to_u (gf_x87.hpp angles_to_u, fr.py:116-162)
+__device__ __forceinline__ cx87 g9_angles_to_u(const Grp9& g, double ang0, double ang1, double ang2, double ang3)
+{
+    const int r = g.r, c = g.c;
+    // lanes (0,0), (1,0), (2,0) evaluate theta12, theta13, theta23; lane (0,1) the phase; the others repeat lane (0,0)'s work
+    const int which = c == 0 ? r : (g.l == 1 ? 3 : 0);
+    // (four scalars, not an array: the compiler turned the selects over ang[] into an indexed load from a stack copy -- scratch)
+    const double a0 = which == 1 ? ang1 : (which == 2 ? ang2 : ang0);
+    x87 a = x_sqrt(x_from(a0));                                       // fr.py:141,145-147
+    if (which == 1) a = x_sqrt(a);
+    const dd da = as_dd(a);
+    const bool small = da.hi <= 0.72;
+    const dd arg = small ? da : dd_cofunc(da);
+    const dd as = dd_asin_small(arg);
+    const bool complement = (which == 1) == small;
+    x87 t = round64(complement ? dd_sub(dd_pio2(), as) : as);
+    if (which == 3) t = x_from(ang3);
+    x87 sn, cs;
+    x_sincos(t, sn, cs);                                              // fr.py:149-154; exp(+-i dcp) = (cos, +-sin)
+    cx87* ex = g.A0;
+    if (c == 0 || g.l == 1) ex[which] = c_make(sn, cs);
+    grp_sync();
+    const cx87 e12 = ex[0], e13 = ex[1], e23 = ex[2], ed = ex[3];
+    grp_sync();
+    const x87 s12 = e12.re, c12 = e12.im, s13 = e13.re, c13 = e13.im, s23 = e23.re, c23 = e23.im, sd = ed.re, cd = ed.im;
+    const cx87 em = c_make(cd, x_neg(sd)), ep = c_make(cd, sd);
+    const cx87 s13em = c_scale(s13, em);                              // p2[0][2]
+    const cx87 ms13ep = c_scale(x_neg(s13), ep);                      // p2[2][0]
+    const x87 zero = x_from(0.0);
+    // T = p1 . p2, row r (as grp_angles_to_u_row)
+    const x87 fa = r == 1 ? s23 : c23, fb = r == 1 ? c23 : x_neg(s23);
+    cx87 T0 = c_scale(fa, ms13ep), T1 = c_make(fb, zero), T2 = c_make(x_mul(fa, c13), zero);
+    if (r == 0) { T0 = c_make(c13, zero); T1 = c_zero(); T2 = s13em; }
+    // u = T . p3, entry c
+    const x87 ga = c == 0 ? c12 : s12, gb = c == 0 ? x_neg(s12) : c12;
+    const cx87 v = c_add(c_scale(ga, T0), c_scale(gb, T1));
+    return c == 2 ? T2 : v;
+}
+
+__device__ __forceinline__ cx87 g9_load(const double* hi, const double* lo, int l)
+{
+    const x87 re = {hi[2 * l], lo[2 * l]}, im = {hi[2 * l + 1], lo[2 * l + 1]};
+    return c_make(re, im);
+}
+
+// entry (r, c) of U diag(0, w1, w2) U^+ (gf_x87.hpp sandwich)
+__device__ __forceinline__ cx87 g9_sandwich(const Grp9& g, cx87 u, double w1, double w2)
+{
+    const x87 xw1 = x_from(w1), xw2 = x_from(w2);
+    cx87* U = g.A0;
+    U[g.l] = u;
+    grp_sync();
+    const cx87 ui1 = U[3 * g.r + 1], ui2 = U[3 * g.r + 2], uj1 = U[3 * g.c + 1], uj2 = U[3 * g.c + 2];
+    grp_sync();
+    const cx87 t1 = c_scale(xw1, c_conj(uj1));                        // (diag . U^+)[1][j]
+    const cx87 t2 = c_scale(xw2, c_conj(uj2));
+    return c_add(c_mul(ui1, t1), c_mul(ui2, t2));
+}
+
+__device__ __forceinline__ void g9_walker_terms(const Grp9& g, const GfCommon& c, const GfBsm& tb, const double* __restrict__ theta,
+                                                int layout, int64_t n, int64_t i, cx87& hs, cx87& hn, int stride = 0)
+{
+    const int ndim = stride ? stride : c.ndim;
+    cx87 u;
+    if (c.idx_sm[0] >= 0) {
+        u = g9_angles_to_u(g, row_value(theta, layout, n, ndim, i, c.idx_sm[0]), row_value(theta, layout, n, ndim, i, c.idx_sm[1]),
+                           row_value(theta, layout, n, ndim, i, c.idx_sm[2]), row_value(theta, layout, n, ndim, i, c.idx_sm[3]));
+    } else {
+        u = g9_load(tb.smu_hi, tb.smu_lo, g.l);
+    }
+    const double m21 = c.idx_mass[0] >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_mass[0]) : c.mass_fixed[0];
+    const double m3x = c.idx_mass[1] >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_mass[1]) : c.mass_fixed[1];
+    hs = g9_sandwich(g, u, m21, m3x);
+    if (tb.texture == TEX_NONE && c.idx_mm[0] >= 0) {
+        u = g9_angles_to_u(g, row_value(theta, layout, n, ndim, i, c.idx_mm[0]), row_value(theta, layout, n, ndim, i, c.idx_mm[1]),
+                           row_value(theta, layout, n, ndim, i, c.idx_mm[2]), row_value(theta, layout, n, ndim, i, c.idx_mm[3]));
+    } else {
+        u = g9_load(tb.npu_hi, tb.npu_lo, g.l);
+    }
+    const double ll = c.idx_scale >= 0 ? row_value(theta, layout, n, ndim, i, c.idx_scale) : c.scale_fixed;
+    const double sc2 = cr_pow10(ll);
+    const double sc1 = sc2 / 100.0;
+    hn = g9_sandwich(g, u, sc1, sc2);
+}
+
+// one energy bin on the nine lanes; every lane returns the same residual
+__device__ __forceinline__ double g9_bin_residual(const Grp9& g, cx87 hs, cx87 hn, double pre, double epow)
+{
+    const int r = g.r, c = g.c, l = g.l;
+    cx87 *M = g.A0, *P = g.A1, *S = g.A2, *X = g.A3;
+    double* sm = g.sm;
+    if (r == c) { sm[2 * r] = fabs(pre * hs.re.hi); sm[2 * r + 1] = fabs(epow * hn.re.hi); }
+    grp_sync();
+    double big = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const double a = sm[i]; big = a > big ? a : big; }
+    grp_sync();
+    double p2 = 1.0;
+    if (big > 0.0 && big < 1.7976931348623157e308) {
+        const int e = (int)((x_bits(big) >> 52) & 0x7ff) - 1023;
+        int k = -e;
+        k = k > 1000 ? 1000 : (k < -1000 ? -1000 : k);
+        p2 = x_from_bits((int64_t)(k + 1023) << 52);
+    }
+    const x87 xp = x_from(pre * p2), xe = x_from(epow * p2);
+    M[l] = c_add(c_scale(xp, hs), c_scale(xe, hn));                                      // fr.py:386, 394-395
+    grp_sync();
+    const x87 two = x_from(2.0), three = x_from(3.0), nine = x_from(9.0), n27 = x_from(27.0);
+    const cx87 tr = c_add(c_add(M[0], M[4]), M[8]);
+    // the nine products of tr H^2 -- entry (r, c) forms h[r][c] h[c][r] -- and, in a second pass, the six inner products of the
+    // determinant (lanes 0-2: h[p][1] h[q][2], lanes 3-5: h[q][1] h[p][2], (p, q) the rows other than l mod 3 in order) and the
+    // three products the eigenvectors share (lane 6: h10 h02, 7: h21 h10, 8: h12 h20)
+    P[l] = c_mul(M[3 * r + c], M[3 * c + r]);
+    {
+        const int rr = l < 3 ? l : (l < 6 ? l - 3 : 0);
+        const int p = rr == 0 ? 1 : 0, q = rr == 2 ? 1 : 2;
+        int i0 = l < 3 ? 3 * p + 1 : 3 * q + 1, i1 = l < 3 ? 3 * q + 2 : 3 * p + 2;
+        if (l == 6) { i0 = 3; i1 = 2; }
+        if (l == 7) { i0 = 7; i1 = 3; }
+        if (l == 8) { i0 = 5; i1 = 6; }
+        S[l] = c_mul(M[i0], M[i1]);
+    }
+    grp_sync();
+    const cx87 h10h02 = S[6], h21h10 = S[7], h12h20 = S[8];
+    {
+        // row r of tr H^2 and term r of the determinant (the three lanes of a row do the same; one of them hands it on)
+        const cx87 srow = c_add(c_add(P[3 * r], P[3 * r + 1]), P[3 * r + 2]);
+        const cx87 drow = c_mul(M[3 * r], c_sub(S[r], S[3 + r]));
+        cx87* ex = reinterpret_cast<cx87*>(sm);
+        if (c == 0) { ex[r] = srow; ex[3 + r] = drow; }
+    }
+    grp_sync();
+    cx87 tr2, det;
+    {
+        const cx87* ex = reinterpret_cast<const cx87*>(sm);
+        tr2 = c_add(c_add(ex[0], ex[1]), ex[2]);
+        det = c_add(c_sub(ex[3], ex[4]), ex[5]);                                          // fr.py:77-79
+    }
+    grp_sync();
+    const cx87 a = c_neg(tr);                                                           // fr.py:204
+    const cx87 a2 = c_mul(tr, tr);                                                      // = a a, bit for bit
+    const cx87 b = c_scale(GFX_X87_HALF, c_sub(a2, tr2));                               // fr.py:205
+    const cx87 cc = c_neg(det);                                                         // fr.py:206
+    const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
+    const cx87 R = c_scale(GFX_X87_54TH,
+                           c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, cc)));   // fr.py:209
+    const cx87 Q3 = c_mul(Q, c_mul(Q, Q));
+    {
+        cx87* ex = reinterpret_cast<cx87*>(sm);
+        const cx87 root = c_sqrt_pos(r == 2 ? Q : Q3);                                   // both square roots of the bin in one pass
+        if (c == 0) ex[r] = root;
+    }
+    grp_sync();
+    cx87 sqQ3, sq;
+    { const cx87* ex = reinterpret_cast<const cx87*>(sm); sqQ3 = ex[0]; sq = ex[2]; }
+    grp_sync();
+    const cx87 theta = c_acos_near_real(c_div(R, sqQ3));                                // fr.py:210
+    const cx87 m2sq = c_scale(x_neg(two), sq);
+    const cx87 third_a = c_scale(GFX_X87_THIRD, a);
+    const x87 pi = {3.141592653589793, 1.22514845490862e-16};
+    const x87 twopi = x_mul(two, pi);
+    // eigenvalue k = r (fr.py:212-214); the three lanes of a row are the components A, B, C of eigenvector k (fr.py:216-226)
+    x87 are = theta.re;
+    if (r == 1) are = x_sub(theta.re, twopi);
+    if (r == 2) are = x_add(theta.re, twopi);
+    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(are, theta.im), three))), third_a);
+    {
+        const cx87 mi = c == 0 ? M[5] : (c == 1 ? M[6] : M[3]);
+        const cx87 mjj = c == 0 ? M[0] : (c == 1 ? M[4] : M[8]);
+        const cx87 sp = c == 0 ? h10h02 : (c == 1 ? h21h10 : h12h20);
+        P[l] = c_sub(c_mul(mi, c_sub(mjj, E)), sp);                                     // A | B | C of eigenvector r
+    }
+    grp_sync();
+    const cx87 A = P[3 * r], B = P[3 * r + 1], C = P[3 * r + 2];
+    // lane c = 0: AB, 1: AC, 2: BC (fr.py:228-230), then the component it owns: x2 = AB / N, x1 = AC / N, x0 = conj(B) C / N
+    const cx87 prod = c_mul(c == 2 ? B : A, c == 0 ? B : C);
+    const cx87 cbc = c_mul(c_conj(B), C);
+    {
+        x87* exx = reinterpret_cast<x87*>(sm);
+        exx[l] = c_abs(prod);
+    }
+    grp_sync();
+    x87 N;
+    {
+        const x87* exx = reinterpret_cast<const x87*>(sm);
+        const x87 ab = exx[3 * r], ac = exx[3 * r + 1], bc = exx[3 * r + 2];
+        N = x_sqrt(x_add(x_add(x_mul(ab, ab), x_mul(ac, ac)), x_mul(bc, bc)));
+    }
+    const x87 rn = x_div(x_from(1.0), N);                                               // fr.py:232-236: x * (1 / d)
+    const cx87 comp = c == 2 ? cbc : prod;
+    X[3 * (2 - c) + r] = c_make(x_mul(comp.re, rn), x_mul(comp.im, rn));                // column r of X
+    grp_sync();
+    // f = |X X^+| (fr.py:489): lanes 0..5 take (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    {
+        const int idx = l < 6 ? l : 5;
+        const int i = idx < 3 ? 0 : (idx < 5 ? 1 : 2);
+        const int j = idx < 3 ? idx : (idx < 5 ? idx - 2 : 2);
+        cx87 sacc = c_mul(X[3 * i + 0], c_conj(X[3 * j + 0]));
+        sacc = c_add(sacc, c_mul(X[3 * i + 1], c_conj(X[3 * j + 1])));
+        sacc = c_add(sacc, c_mul(X[3 * i + 2], c_conj(X[3 * j + 2])));
+        x87* exx = reinterpret_cast<x87*>(sm) + 12;                                     // (the norms above may still be being read)
+        if (l < 6) exx[idx] = c_abs(sacc);
+    }
+    grp_sync();
+    double res;
+    {
+        const x87* exx = reinterpret_cast<const x87*>(sm) + 12;
+        const x87 f00 = exx[0], f01 = exx[1], f02 = exx[2], f11 = exx[3], f12 = exx[4], f22 = exx[5];
+        const x87 trf = x_add(x_add(f00, f11), f22);
+        const x87 sum = x_add(x_add(x_add(x_add(f00, f01), x_add(f02, f01)), x_add(x_add(f11, f12), x_add(f02, f12))), f22);
+        const double rt = fabs(x_to_double(x_sub(trf, three))), rs = fabs(x_to_double(x_sub(sum, three)));
+        res = rt > rs ? rt : rs;
+        if (!(res == res) || !(rt == rt) || !(rs == rs)) res = INFINITY;
+    }
+    grp_sync();
+    return res;
+}
+
+// The two teams behind one face, so that the kernels below are written once.
+struct Team3 {
+    static constexpr int LANES = GRP, PER_WAVE = GRP_PER_WAVE, DOUBLES = GRP_DOUBLES;
+    Grp g;
+    cx87 hs[3], hn[3];
+    __device__ __forceinline__ void init(double* base, int lane_in_group) { g.M = reinterpret_cast<cx87*>(base); g.ex = reinterpret_cast<cx87*>(base + 36); g.r = lane_in_group; }
+    __device__ __forceinline__ bool leader() const { return g.r == 0; }
+    __device__ __forceinline__ void terms(const GfCommon& c, const GfBsm& tb, const double* theta, int layout, int64_t n, int64_t i, int stride)
+    { grp_walker_terms(g, c, tb, theta, layout, n, i, hs, hn, stride); }
+    __device__ __forceinline__ double bin(double pre, double epow, long long* tick = nullptr) { return grp_bin_residual(g, hs, hn, pre, epow, tick); }
+};
+struct Team9 {
+    static constexpr int LANES = G9, PER_WAVE = G9_PER_WAVE, DOUBLES = G9_DOUBLES;
+    Grp9 g;
+    cx87 hs, hn;
+    __device__ __forceinline__ void init(double* base, int lane_in_group)
+    {
+        g.A0 = reinterpret_cast<cx87*>(base); g.A1 = g.A0 + 9; g.A2 = g.A1 + 9; g.A3 = g.A2 + 9; g.sm = base + 144;
+        g.l = lane_in_group; g.r = lane_in_group / 3; g.c = lane_in_group - 3 * g.r;
+    }
+    __device__ __forceinline__ bool leader() const { return g.l == 0; }
+    __device__ __forceinline__ void terms(const GfCommon& c, const GfBsm& tb, const double* theta, int layout, int64_t n, int64_t i, int stride)
+    { g9_walker_terms(g, c, tb, theta, layout, n, i, hs, hn, stride); }
+    __device__ __forceinline__ double bin(double pre, double epow, long long* = nullptr) { return g9_bin_residual(g, hs, hn, pre, epow); }
+};
+
 // Fan-out of a short queue.  A walker's bins are evaluated one after the other by one group -- right for throughput, but a
 // queue with fewer walkers than the grid has groups leaves most of the GPU idle behind the critical path of the walker with
 // the most bins (nine bins: ~0.4 ms).  So with `count` walkers and `groups` groups in the grid every walker is cut into
@@ -485,13 +747,14 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
 __device__ unsigned long long g_settle_t[12];
 __device__ unsigned long long g_settle_c[4];      // shader-clock counts: [0] sum over launches of the longest (terms), [1] of the longest (terms + bin)
 __device__ unsigned long long g_settle_cmax[4];
-#define GF_ST_MARK(i) do { if (g.r == 0) { atomicMax(&g_settle_t[i], (unsigned long long)wall_clock64()); if (i <= 2) atomicMax(&g_settle_cmax[i], (unsigned long long)(clock64() - c_entry)); } } while (0)
+#define GF_ST_MARK(i) do { if (lead) { atomicMax(&g_settle_t[i], (unsigned long long)wall_clock64()); if (i <= 2) atomicMax(&g_settle_cmax[i], (unsigned long long)(clock64() - c_entry)); } } while (0)
 #else
 #define GF_ST_MARK(i) do { } while (0)
 #endif
+template <class Team>
 __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(const GfSettleArgs s)
 {
-    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * Team::PER_WAVE * Team::DOUBLES];
     GfArbQueue* __restrict__ uq = s.pq;
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
     // nothing parked -- the usual case wherever a posterior keeps away from the failing region: nothing to settle and nothing to
@@ -504,15 +767,11 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
 #endif
     {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane / GRP;
-    const bool active = grp < GRP_PER_WAVE;
-    Grp g;
-    {
-        double* base = lds + ((size_t)wave * GRP_PER_WAVE + (active ? grp : 0)) * GRP_DOUBLES;
-        g.M = reinterpret_cast<cx87*>(base);
-        g.ex = reinterpret_cast<cx87*>(base + 36);
-        g.r = lane - grp * GRP;
-    }
+    const int grp = lane / Team::LANES;
+    const bool active = grp < Team::PER_WAVE;
+    Team tm;
+    tm.init(lds + ((size_t)wave * Team::PER_WAVE + (active ? grp : 0)) * Team::DOUBLES, lane - grp * Team::LANES);
+    const bool lead = tm.leader();
     const int ndim = s.ndim, nhalf = s.nwalkers / 2;
     const int64_t nprop = (int64_t)s.nchains * nhalf;
     const int64_t run_step = s.state->run_step_base + s.step_offset;
@@ -522,9 +781,8 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     // A half-step waits for this kernel, and a handful of parked proposals is the usual case: what counts is the critical path
     // of ONE walker, so its bins are spread over as many groups as the grid has to spare (uni_fanout).  The last part of a
     // walker to finish completes its update.
-    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE);
+    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * Team::PER_WAVE);
     const unsigned long long vcount = (unsigned long long)count * fan;
-    cx87 hs[3], hn[3];
     unsigned long long mask = 0ull;
     int64_t t = -1;
     int chain = 0;
@@ -533,14 +791,14 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     unsigned int warm = 0u;
     for (;;) {
         const bool need = !exhausted && !mine;
-        const unsigned long long nb = __ballot(need && g.r == 0);
+        const unsigned long long nb = __ballot(need && lead);
         if (nb != 0ull) {
             unsigned int base = 0;
             const int leader = __ffsll((long long)nb) - 1;
             if (lane == leader) base = atomicAdd(&uq->head, (unsigned int)__popcll(nb));
             base = (unsigned int)__shfl((int)base, leader);
             if (need) {
-                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
+                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * Team::LANES)) - 1ull));
                 if (idx < vcount) {
                     const GfArbItem it = uq->items[idx / fan];
                     t = (int64_t)it.walker;
@@ -560,13 +818,14 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                         // are only looked at when the kernel ends.
                         {
                             const int kb = 63 - __clzll((long long)mask);
-                            const void* lines[12] = {&c.idx_sm[0], &c.idx_mass[0], &c.mass_fixed[0], &c.idx_scale, &c.scale_fixed, &c.idx_mm[0], &tb.texture,
-                                                     &tb.npu_hi[6 * g.r], &tb.npu_lo[6 * g.r], &tb.inv2e[kb], &tb.epow[kb],
-                                                     s.pend_rows + (size_t)t * GF_PEND_STRIDE};
-#pragma unroll
-                            for (int q = 0; q < 12; ++q) warm ^= *static_cast<const volatile unsigned int*>(lines[q]);
+#define GF_TOUCH(p) warm ^= *reinterpret_cast<const volatile unsigned int*>(p)
+                            GF_TOUCH(&c.idx_sm[0]); GF_TOUCH(&c.idx_mass[0]); GF_TOUCH(&c.mass_fixed[0]); GF_TOUCH(&c.idx_scale);
+                            GF_TOUCH(&c.scale_fixed); GF_TOUCH(&c.idx_mm[0]); GF_TOUCH(&tb.texture); GF_TOUCH(&tb.npu_hi[0]);
+                            GF_TOUCH(&tb.npu_lo[0]); GF_TOUCH(&tb.inv2e[kb]); GF_TOUCH(&tb.epow[kb]);
+                            GF_TOUCH(s.pend_rows + (size_t)t * GF_PEND_STRIDE);
+#undef GF_TOUCH
                         }
-                        grp_walker_terms(g, c, tb, s.pend_rows, 0, nprop, t, hs, hn, GF_PEND_STRIDE);
+                        tm.terms(c, tb, s.pend_rows, 0, nprop, t, GF_PEND_STRIDE);
                         GF_ST_MARK(1);
                     }
                 } else {
@@ -581,13 +840,13 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                 const GfBsm* tbp = s.multi ? s.tbs[chain] : s.tb;
                 const int k = 63 - __clzll((long long)mask);
                 mask &= ~(1ull << k);
-                const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+                const double res = tm.bin(tbp->inv2e[k], tbp->epow[k]);
                 GF_ST_MARK(2);
                 if (!(res < 1e-7)) { failed = true; mask = 0ull; }      // fr.py:493-494: the reference raises
             }
             if (mask == 0ull) {
                 mine = false;
-                if (g.r == 0) {
+                if (lead) {
                     // report this part; the last part of the walker to report completes the walker's half-step
                     // (gf_sampler.hip stretch_body, after proposal_lnprob)
                     if (failed) atomicOr(&s.ctl[2 * t + 1], 1u);
@@ -665,29 +924,26 @@ __global__ __launch_bounds__(64) void k_uni_debug_serial(const GfCommon* __restr
     }
 }
 
+template <class Team>
 __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                                const double* __restrict__ theta, int layout, int64_t n,
                                                                const int64_t* __restrict__ walkers, const int32_t* __restrict__ bins, int64_t npairs,
                                                                double* __restrict__ out, int timing)
 {
-    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * Team::PER_WAVE * Team::DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane / GRP;
-    if (grp >= GRP_PER_WAVE) return;
-    Grp g;
-    double* base = lds + ((size_t)wave * GRP_PER_WAVE + grp) * GRP_DOUBLES;
-    g.M = reinterpret_cast<cx87*>(base);
-    g.ex = reinterpret_cast<cx87*>(base + 36);
-    g.r = lane - grp * GRP;
-    const int64_t groups = (int64_t)gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE;
-    for (int64_t t = ((int64_t)blockIdx.x * (UNI_BLOCK / 64) + wave) * GRP_PER_WAVE + grp; t < npairs; t += groups) {
-        cx87 hs[3], hn[3];
+    const int grp = lane / Team::LANES;
+    if (grp >= Team::PER_WAVE) return;
+    Team tm;
+    tm.init(lds + ((size_t)wave * Team::PER_WAVE + grp) * Team::DOUBLES, lane - grp * Team::LANES);
+    const int64_t groups = (int64_t)gridDim.x * (UNI_BLOCK / 64) * Team::PER_WAVE;
+    for (int64_t t = ((int64_t)blockIdx.x * (UNI_BLOCK / 64) + wave) * Team::PER_WAVE + grp; t < npairs; t += groups) {
         const long long c0 = clock64();
         const long long w0 = wall_clock64();
-        grp_walker_terms(g, *cp, *tbp, theta, layout, n, walkers[t], hs, hn);
+        tm.terms(*cp, *tbp, theta, layout, n, walkers[t], 0);
         const long long c1 = clock64();
         long long tick[5] = {0, 0, 0, 0, 0};
-        const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[bins[t]], tbp->epow[bins[t]], timing >= 3 ? tick : nullptr);
+        const double res = tm.bin(tbp->inv2e[bins[t]], tbp->epow[bins[t]], timing >= 3 ? tick : nullptr);
         const long long c2 = clock64();
         // timing (tools/arb_latency_probe.py): shader-clock cycles of the walker's terms / of the bin / of the bin's sections
         // instead of the residual
@@ -702,7 +958,7 @@ __global__ __launch_bounds__(UNI_BLOCK) void k_uni_debug_group(const GfCommon* _
         if (timing == 8) o = (double)(c2 - tick[4]);        // |X X^+|, sums
         if (timing == 9) o = (double)(c2 - c0) / (10.0 * (double)(wall_clock64() - w0));   // clock64 counts per ns of the 100 MHz wall clock
         if (timing == 10) o = 10.0 * (double)(wall_clock64() - w0);                         // terms + bin in ns of the wall clock
-        if (g.r == 0) out[t] = o;
+        if (tm.leader()) out[t] = o;
     }
 }
 
@@ -727,7 +983,7 @@ extern "C" int gf_internal_settle_timing(unsigned long long* out, int reset)
 // graph and runs after every half-step, almost always on an empty queue -- where its cost is the launch)
 hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t s)
 {
-    constexpr int64_t per_block = (UNI_BLOCK / 64) * (64 / 3);
+    constexpr int64_t per_block = (UNI_BLOCK / 64) * Team9::PER_WAVE;
     const int64_t nprop = (int64_t)a.nchains * (a.nwalkers / 2);
     // enough groups to spread a short queue's walkers over (fan-out); on an empty queue every block returns after one load.  One
     // block per CU: measured on the C5 scan's sampling phase (256 chains x 512 walkers, a few hundred parked proposals per
@@ -738,7 +994,7 @@ hipError_t gf_launch_stretch_settle(const GfSettleArgs& a, int cus, hipStream_t 
     if (blocks < 1) blocks = 1;
     static const int forced = [] { const char* e = gf_internal_env("GF_SETTLE_BLOCKS", 0); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
     if (forced > 0) blocks = forced;
-    hipLaunchKernelGGL(k_stretch_settle, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_stretch_settle<Team9>, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -747,7 +1003,8 @@ hipError_t gf_launch_uni_debug(const GfCommon* d_common, const GfBsm* d_bsm, con
                                const int32_t* bins, int64_t npairs, int which, double* out, hipStream_t s)
 {
     if (which == 0) hipLaunchKernelGGL(k_uni_debug_serial, dim3(512), dim3(64), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out);
-    else hipLaunchKernelGGL(k_uni_debug_group, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out, which - 1);
+    else if (which >= 100) hipLaunchKernelGGL(k_uni_debug_group<Team9>, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out, which - 100);
+    else hipLaunchKernelGGL(k_uni_debug_group<Team3>, dim3(512), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, walkers, bins, npairs, out, which - 1);
     return hipGetLastError();
 }
 

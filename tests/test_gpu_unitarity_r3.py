@@ -62,8 +62,11 @@ def test_three_lane_chain_equals_the_serial_chain_bit_for_bit(dim, tex, twelve, 
         bins = np.tile(np.arange(20), n)
         serial = _residuals(m, d_th, n, walkers, bins, 0)
         group = _residuals(m, d_th, n, walkers, bins, 1)
+        nine = _residuals(m, d_th, n, walkers, bins, 100)          # the nine-lane distribution (the sampler's settle step)
     assert np.array_equal(serial.view(np.uint64), group.view(np.uint64)), \
         "%d of %d residuals differ" % (np.sum(serial.view(np.uint64) != group.view(np.uint64)), len(serial))
+    assert np.array_equal(serial.view(np.uint64), nine.view(np.uint64)), \
+        "nine lanes: %d of %d residuals differ" % (np.sum(serial.view(np.uint64) != nine.view(np.uint64)), len(serial))
     assert np.isfinite(serial).mean() > 0.99
     # and the chain itself against the oracle (long double: the reference's arithmetic): worst bin per walker, verdict equal
     # outside half a decade around the threshold

@@ -33,7 +33,7 @@ with Model(compile_model(ps, "BSM_GAUSS", texture=Texture.OEU, **kw)) as m:
         w = np.arange(npairs, dtype=np.int64) % n
         b = (np.arange(npairs) % 20).astype(np.int32)
         d_w, d_b, d_o = m.alloc(w.nbytes).upload(w), m.alloc(b.nbytes).upload(b), m.alloc(8 * npairs)
-        for which, label in ((2, "walker terms"), (3, "one bin"), (4, " bin: scaling + H"), (5, " bin: tr, tr H^2, det"), (6, " bin: Q, R, sqrt, /, arccos"),
+        for which, label in ((101, "NINE lanes: walker terms"), (102, "NINE lanes: one bin"), (110, "NINE lanes: terms + bin, wall ns"), (2, "walker terms"), (3, "one bin"), (4, " bin: scaling + H"), (5, " bin: tr, tr H^2, det"), (6, " bin: Q, R, sqrt, /, arccos"),
                              (7, " bin: sqrt Q, cos, eigenvalue"), (8, " bin: eigenvector"), (9, " bin: |X X^+|, sums"), (10, "clock64 counts per wall-clock ns"), (11, "terms + bin, wall-clock ns")):
             L.gf_internal_uni_residuals(m._h, d_th.ptr, 0, n, d_w.ptr, d_b.ptr, npairs, which, d_o.ptr)
             L.gf_internal_uni_residuals(m._h, d_th.ptr, 0, n, d_w.ptr, d_b.ptr, npairs, which, d_o.ptr)
