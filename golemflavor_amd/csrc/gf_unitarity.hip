@@ -652,44 +652,40 @@ __device__ __forceinline__ unsigned long long uni_part_mask(unsigned long long m
 // down -- one bin per round of the wave -- until one fails (the walker is non-unitary: fr.py:398-399 raises on the first
 // failing energy) or none is left; then it fetches the next walker.  Every wave leaves when the queue is exhausted and all its
 // groups have finished their walker: the exit condition is reached whatever the other waves do.
+template <class Team>
 __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                            const double* __restrict__ theta, int layout, int64_t n,
                                                            double* __restrict__ lnprob, int32_t* __restrict__ status,
                                                            GfArbQueue* __restrict__ uq, GfUniQueue* __restrict__ wq, unsigned int* __restrict__ seen)
 {
-    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * GRP_PER_WAVE * GRP_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[(UNI_BLOCK / 64) * Team::PER_WAVE * Team::DOUBLES];
     const unsigned int count = uq->count < uq->cap ? uq->count : uq->cap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane / GRP;
-    const bool active = grp < GRP_PER_WAVE;                             // lane 63 has no group
-    Grp g;
-    {
-        double* base = lds + ((size_t)wave * GRP_PER_WAVE + (active ? grp : 0)) * GRP_DOUBLES;
-        g.M = reinterpret_cast<cx87*>(base);
-        g.ex = reinterpret_cast<cx87*>(base + 36);
-        g.r = lane - grp * GRP;
-    }
-    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * GRP_PER_WAVE);
+    const int grp = lane / Team::LANES;
+    const bool active = grp < Team::PER_WAVE;                           // lane 63 has no group
+    Team tm;
+    tm.init(lds + ((size_t)wave * Team::PER_WAVE + (active ? grp : 0)) * Team::DOUBLES, lane - grp * Team::LANES);
+    const bool lead = tm.leader();
+    const unsigned int fan = uni_fanout(count, gridDim.x * (UNI_BLOCK / 64) * Team::PER_WAVE);
     const unsigned long long vcount = (unsigned long long)count * fan;  // (walker, part) items; count <= 2^23, fan <= 20
-    cx87 hs[3], hn[3];
     unsigned long long mask = 0ull;
     int64_t wi = -1;
     bool exhausted = !active;                                           // this group found the queue empty
     for (;;) {
         const bool need = !exhausted && mask == 0ull;
-        const unsigned long long nb = __ballot(need && g.r == 0);       // one request per group
+        const unsigned long long nb = __ballot(need && lead);           // one request per group
         if (nb != 0ull) {
             unsigned int base = 0;
             const int leader = __ffsll((long long)nb) - 1;
             if (lane == leader) base = atomicAdd(&uq->head, (unsigned int)__popcll(nb));
             base = (unsigned int)__shfl((int)base, leader);
             if (need) {
-                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * GRP)) - 1ull));
+                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * Team::LANES)) - 1ull));
                 if (idx < vcount) {
                     const GfArbItem it = uq->items[idx / fan];
                     wi = (int64_t)it.walker;
                     mask = wi < n ? uni_part_mask(it.mask, idx % fan, fan) : 0ull;
-                    if (mask != 0ull) grp_walker_terms(g, *cp, *tbp, theta, layout, n, wi, hs, hn);
+                    if (mask != 0ull) tm.terms(*cp, *tbp, theta, layout, n, wi, 0);
                 } else {
                     exhausted = true;
                 }
@@ -700,9 +696,9 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
         if (mask != 0ull) {
             const int k = 63 - __clzll((long long)mask);                // the highest undecided energy first: the likeliest to fail
             mask &= ~(1ull << k);
-            const double res = grp_bin_residual(g, hs, hn, tbp->inv2e[k], tbp->epow[k]);
+            const double res = tm.bin(tbp->inv2e[k], tbp->epow[k]);
             if (!(res < 1e-7)) {                                        // fr.py:493-494 (NaN raises too)
-                if (g.r == 0) {
+                if (lead) {
                     status[wi] = ST_NON_UNITARY;
                     if (lnprob) lnprob[wi] = __longlong_as_double(0x7ff8000000000000LL);
                 }
@@ -1038,6 +1034,11 @@ hipError_t gf_launch_uni_resolve(const GfCommon* d_common, const GfBsm* d_bsm, c
     if (blocks < floor_blocks) blocks = floor_blocks;
     static const int forced = [] { const char* e = gf_internal_env("GF_UNI_RESOLVE_BLOCKS", 0); return e ? std::atoi(e) : 0; }();   // diagnostics / A-B
     if (forced > 0) blocks = forced;
-    hipLaunchKernelGGL(k_uni_resolve, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);
+    // A short queue is a latency: nine lanes per walker (one per matrix entry: 39 us for a walker's terms and one bin against 70 us on
+    // three lanes); a long one is throughput: three lanes waste fewer on the scalar part of the chain.
+    if (expect <= 2048 && forced == 0)
+        hipLaunchKernelGGL(k_uni_resolve<Team9>, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);
+    else
+        hipLaunchKernelGGL(k_uni_resolve<Team3>, dim3((unsigned)blocks), dim3(UNI_BLOCK), 0, s, d_common, d_bsm, theta, layout, n, lnprob, status, uq, wq, seen);
     return hipGetLastError();
 }
