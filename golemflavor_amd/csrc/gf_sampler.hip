@@ -246,8 +246,11 @@ __device__ __forceinline__ void stretch_body(const GfCommon& c, const GfBsm* __r
 }
 
 // every ensemble samples the same posterior: constants by value (scalar registers), walkers packed densely
+#ifndef GF_STRETCH_WAVES
+#define GF_STRETCH_WAVES 2      // blocks of 256 threads per CU the half-step kernels are compiled for (A/B: tools/build_variants.sh)
+#endif
 template <int NDIM, int MODE, int LPW>
-__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
+__global__ __launch_bounds__(GF_BLOCK, GF_STRETCH_WAVES) void k_stretch(const GfCommon c, const GfBsm* __restrict__ tb,
                                                           const double* __restrict__ ptab, const StretchArgs s)
 {
     const int nhalf = s.nwalkers / 2;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch(const GfCommon c, const
 // one posterior per ensemble (grid scans, SURVEY.md 8(e) "all chains of a GPU stacked into one launch"):
 // blockIdx.y = chain, so that a block's constants are block-uniform and come from scalar loads
 template <int NDIM, int MODE, int LPW>
-__global__ __launch_bounds__(GF_BLOCK, 2) void k_stretch_multi(const StretchArgs s)
+__global__ __launch_bounds__(GF_BLOCK, GF_STRETCH_WAVES) void k_stretch_multi(const StretchArgs s)
 {
     const int chain = blockIdx.y;
     const int t = blockIdx.x * GF_BLOCK + threadIdx.x;
