@@ -328,6 +328,7 @@ struct PersistArgs {
     int32_t thin, store;
     double a;
     const uint64_t* stream_ids;     // as StretchArgs::stream_ids
+    int32_t workers;                // threads that move walkers; the block's other threads (if any) draw the random numbers one half-step ahead
 };
 
 // MAXT: the largest workgroup the instance is compiled for.  1024 threads would cap the kernel at 128 VGPRs, which the
@@ -344,19 +345,53 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
     const double* __restrict__ ptab = s.ptabs[s.nmodels > 1 ? chain : 0];
     const int ndim = NDIM ? NDIM : c.ndim;
     const int nw = s.nwalkers, nhalf = nw / 2, nt = blockDim.x;
-    // LDS: ctab[64] | pos[nw][ndim] | lnp[nw] | rows[nt][ndim] | naccept[nw] (u32)
+    // Workers and producers.  A half-step's random quantities -- the stretch factor z, the partner j and the left side of the
+    // accept test, ln(z^(ndim-1) / u) -- depend on nothing but the counters, a third of a half-step's instructions (Philox4x32-10,
+    // the conversions, a logarithm) on the one wave the reference's 100-walker chain runs on.  With `workers` < blockDim the
+    // block's other threads compute them ONE HALF-STEP AHEAD into a double-buffered LDS table while the workers move the
+    // walkers; the barrier that separates the half-steps anyway hands the table over.  Same expressions, same values: the chain
+    // is bitwise the one-wave chain (tests).
+    const int ntw = s.workers > 0 && s.workers < nt ? s.workers : nt;        // worker threads
+    const int ntp = nt - ntw;                                                // producer threads (0: the workers draw for themselves)
+    const bool producer = (int)threadIdx.x >= ntw;
+    // LDS: ctab[64] | pos[nw][ndim] | lnp[nw] | rows[ntw][ndim] | naccept[nw] (u32) | [producers: z[2][nhalf] | lhs[2][nhalf] | j[2][nhalf]]
     double* ctab = dyn;
     double* pos = ctab + GF_MAX_DIM * 4;
     double* lnp = pos + (size_t)nw * ndim;
     double* rows = lnp + nw;
-    uint32_t* nacc = reinterpret_cast<uint32_t*>(rows + (size_t)nt * ndim);
+    uint32_t* nacc = reinterpret_cast<uint32_t*>(rows + (size_t)ntw * ndim);
+    double* dz = reinterpret_cast<double*>(nacc + ((nw + 1) & ~1));
+    double* dlhs = dz + 2 * (size_t)nhalf;
+    int* dj = reinterpret_cast<int*>(dlhs + 2 * (size_t)nhalf);
     if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
     const int64_t cw = (int64_t)chain * nw;
     for (int i = threadIdx.x; i < nw * ndim; i += nt) pos[i] = s.pos[cw * ndim + i];
     for (int i = threadIdx.x; i < nw; i += nt) { lnp[i] = s.lnp[cw + i]; nacc[i] = s.naccept[cw + i]; }
-    __syncthreads();
-    double* row = rows + (size_t)threadIdx.x * ndim;
+    double* row = rows + (size_t)(producer ? 0 : threadIdx.x) * ndim;
     const uint32_t k0 = (uint32_t)s.seed, k1 = (uint32_t)(s.seed >> 32);
+    const uint64_t gbase = (s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain) * (uint64_t)nhalf;
+    // the draws of walker slot k at half-step counter ctr
+    auto draw = [&](int k, uint64_t ctr, double& z, int& j, double& lhs) {
+        const uint64_t g = gbase + (uint64_t)k;
+        uint32_t r[4];
+        philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r);
+        const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+        j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
+        const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+        const double zr = fma(s.a - 1.0, u1, 1.0);
+        z = zr * zr / s.a;
+        double zp = 1.0;
+        for (int d = 1; d < ndim; ++d) zp *= z;
+        lhs = log(zp / u3);
+    };
+    const uint64_t ctr_first = 2 * s.iteration_base, ctr_end = ctr_first + 2 * (uint64_t)s.nsteps;
+    if (producer && s.nsteps > 0)
+        for (int k = (int)threadIdx.x - ntw; k < nhalf; k += ntp) {
+            double z, lhs; int j;
+            draw(k, ctr_first, z, j, lhs);
+            dz[k] = z; dlhs[k] = lhs; dj[k] = j;                     // buffer 0 = (ctr_first & 1) * nhalf: see below
+        }
+    __syncthreads();
 
     for (int64_t step = 0; step < s.nsteps; ++step) {
         const uint64_t iteration = s.iteration_base + (uint64_t)step;
@@ -365,16 +400,21 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
         for (int half = 0; half < 2; ++half) {
             const int cbase = (1 - half) * nhalf;
             const uint64_t ctr = 2 * iteration + half;
-            for (int k = threadIdx.x; k < nhalf; k += nt) {
-                const uint64_t g = (s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain) * (uint64_t)nhalf + (uint64_t)k;
+            const size_t buf = (size_t)(half) * nhalf;                // ctr_first is even: the buffer of counter ctr is its parity
+            if (producer) {
+                if (ctr + 1 < ctr_end)
+                    for (int k = (int)threadIdx.x - ntw; k < nhalf; k += ntp) {
+                        double z, lhs; int j;
+                        draw(k, ctr + 1, z, j, lhs);
+                        const size_t nb = (size_t)(1 - half) * nhalf;
+                        dz[nb + k] = z; dlhs[nb + k] = lhs; dj[nb + k] = j;
+                    }
+            } else
+            for (int k = threadIdx.x; k < nhalf; k += ntw) {
                 const int w = half * nhalf + k;
-                uint32_t r[4];
-                philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r);
-                const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
-                const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
-                const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
-                const double zr = fma(s.a - 1.0, u1, 1.0);
-                const double z = zr * zr / s.a;
+                double z, lhs; int j;
+                if (ntp > 0) { z = dz[buf + k]; lhs = dlhs[buf + k]; j = dj[buf + k]; }
+                else draw(k, ctr, z, j, lhs);
                 double* sk = pos + (size_t)w * ndim;
                 const double* cj = pos + (size_t)(cbase + j) * ndim;
 #pragma unroll
@@ -387,9 +427,6 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
                 unsigned long long pending;
                 const double lnq = proposal_lnprob<NDIM, MODE, 1>(c, nullptr, ctab, nullptr, row, ndim, st, 0, nullptr, pending);
                 const double lnk = lnp[w];
-                double zp = 1.0;
-                for (int d = 1; d < ndim; ++d) zp *= z;
-                const double lhs = log(zp / u3);
                 const bool accept = lhs > lnk - lnq;
                 if (accept) {
 #pragma unroll
@@ -410,7 +447,7 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
                     if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = lnp[w];
                 }
             }
-            __syncthreads();                                      // the other half moves next: it reads these walkers
+            __syncthreads();                                      // the other half moves next: it reads these walkers (and the next draws are in place)
         }
     }
     for (int i = threadIdx.x; i < nw * ndim; i += nt) s.pos[cw * ndim + i] = pos[i];
@@ -418,15 +455,21 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
 }
 
 // threads and dynamic LDS of the persistent kernel; lds == 0: the ensemble does not fit one workgroup
-inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds)
+inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds, int* workers = nullptr)
 {
     const int nhalf = nwalkers / 2;
     int nt = ((nhalf + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
     if (nt > 512) nt = 512;       // a workgroup of 1024 threads is capped at 128 VGPRs, which the likelihood instances overflow (32-256 B of
                                   // scratch per lane inside the step loop); the half-ensemble loop strides by the block size anyway
-    const size_t bytes = sizeof(double) * ((size_t)GF_MAX_DIM * 4 + (size_t)nwalkers * ndim + nwalkers + (size_t)nt * ndim) +
-                         sizeof(uint32_t) * (size_t)nwalkers;
-    *threads = nt;
+    // as many producer threads again while the block stays within 512 threads (k_stretch_persist)
+    static const bool no_producers = gf_internal_env("GF_SAMPLER_NO_PRODUCERS", 0) != nullptr;       // diagnostics / A-B
+    const size_t base = sizeof(double) * ((size_t)GF_MAX_DIM * 4 + (size_t)nwalkers * ndim + nwalkers + (size_t)nt * ndim) +
+                        sizeof(uint32_t) * (size_t)((nwalkers + 1) & ~1);
+    const size_t draws = (sizeof(double) * 4 + sizeof(int) * 2) * (size_t)nhalf;
+    const bool producers = nt <= 256 && !no_producers && base + draws <= 64 * 1024;
+    const size_t bytes = base + (producers ? draws : 0);
+    if (workers) *workers = nt;
+    *threads = producers ? 2 * nt : nt;
     *lds = (bytes <= 64 * 1024 && nhalf <= 4 * 1024) ? bytes : 0;
 }
 
@@ -893,7 +936,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     {
         int threads = 0;
         size_t lds = 0;
-        persist_geometry(s->nwalkers, s->ndim, &threads, &lds);
+        int workers = 0;
+        persist_geometry(s->nwalkers, s->ndim, &threads, &lds, &workers);
         const char* env = gf_internal_env("GF_SAMPLER_PERSIST", 0);          // "0": always the per-half-step grid kernels
         if (c->mode != MODE_BSM_GAUSS && lds > 0 && !(env && env[0] == '0')) {
             PersistArgs pa;
@@ -902,6 +946,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             pa.chain = store ? s->d_chain : nullptr; pa.lnp_chain = store ? s->d_lnp_chain : nullptr;
             pa.nstore_cap = s->nstore_cap; pa.seed = s->seed; pa.thin = thin; pa.store = store ? 1 : 0; pa.a = s->a;
             pa.stream_ids = s->d_stream_ids;
+            pa.workers = workers;
             constexpr int64_t CHUNK = 1 << 16;                          // steps per launch: bounds a kernel's run time
             int64_t done_p = 0;
             while (done_p < nsteps) {
