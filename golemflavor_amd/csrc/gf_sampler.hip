@@ -455,18 +455,20 @@ __global__ __launch_bounds__(MAXT) void k_stretch_persist(const PersistArgs s)
 }
 
 // threads and dynamic LDS of the persistent kernel; lds == 0: the ensemble does not fit one workgroup
-inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds, int* workers = nullptr)
+inline void persist_geometry(int nwalkers, int ndim, int* threads, size_t* lds, int* workers = nullptr, int nchains = 1, int cus = 256)
 {
     const int nhalf = nwalkers / 2;
     int nt = ((nhalf + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
     if (nt > 512) nt = 512;       // a workgroup of 1024 threads is capped at 128 VGPRs, which the likelihood instances overflow (32-256 B of
                                   // scratch per lane inside the step loop); the half-ensemble loop strides by the block size anyway
-    // as many producer threads again while the block stays within 512 threads (k_stretch_persist)
+    // as many producer threads again while the block stays within 512 threads (k_stretch_persist) -- where a chain's LATENCY is what
+    // counts: up to two ensembles per CU one 100-walker chain steps in 3.6 us instead of 4.1; with the GPU full of ensembles the
+    // producers only take issue slots and LDS from the workers (4096 chains: 2.8e10 evals/s against 3.9e10; tools/bench_c1_chains.py)
     static const bool no_producers = gf_internal_env("GF_SAMPLER_NO_PRODUCERS", 0) != nullptr;       // diagnostics / A-B
     const size_t base = sizeof(double) * ((size_t)GF_MAX_DIM * 4 + (size_t)nwalkers * ndim + nwalkers + (size_t)nt * ndim) +
                         sizeof(uint32_t) * (size_t)((nwalkers + 1) & ~1);
     const size_t draws = (sizeof(double) * 4 + sizeof(int) * 2) * (size_t)nhalf;
-    const bool producers = nt <= 256 && !no_producers && base + draws <= 64 * 1024;
+    const bool producers = nt <= 256 && !no_producers && base + draws <= 64 * 1024 && nchains <= 2 * cus;
     const size_t bytes = base + (producers ? draws : 0);
     if (workers) *workers = nt;
     *threads = producers ? 2 * nt : nt;
@@ -937,7 +939,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         int threads = 0;
         size_t lds = 0;
         int workers = 0;
-        persist_geometry(s->nwalkers, s->ndim, &threads, &lds, &workers);
+        persist_geometry(s->nwalkers, s->ndim, &threads, &lds, &workers, s->nchains, s->cus);
         const char* env = gf_internal_env("GF_SAMPLER_PERSIST", 0);          // "0": always the per-half-step grid kernels
         if (c->mode != MODE_BSM_GAUSS && lds > 0 && !(env && env[0] == '0')) {
             PersistArgs pa;
