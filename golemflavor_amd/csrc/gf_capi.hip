@@ -3,6 +3,7 @@
 // management and the launch calls.  There is deliberately no CPU evaluation path in this library.
 #include <hip/hip_runtime.h>
 #include <pthread.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <cmath>
@@ -1425,12 +1426,24 @@ int gf_host_prepare_n(void* buf, size_t bytes, int threads)
     if (threads > 0) nt = (size_t)(threads > 64 ? 64 : threads);
     if (const char* e = gf_internal_env("GF_PREPARE_THREADS", 0)) { const long k = std::atol(e); if (k >= 1 && k <= 64) nt = (size_t)k; }   // A/B
     if (bytes / min_per_thread < nt) nt = bytes / min_per_thread ? bytes / min_per_thread : 1;
-    // an atomic OR with zero: a write access (the page is mapped writable, not to the shared zero page) that leaves the content
-    // alone and cannot lose a byte another thread stores at the same moment -- so a buffer may be prepared WHILE a copy fills it
+    // Mapping WITHOUT touching the content, so that a buffer may be prepared while a copy fills it: madvise(MADV_POPULATE_WRITE)
+    // (Linux 5.14+: the kernel faults the range in writable, in one call per thread's share), and where that is refused a locked
+    // OR of zero into one byte per page -- written in assembly: the compiler turns an __atomic_fetch_or(p, 0) into a LOAD, and a
+    // load of an untouched anonymous page maps the shared zero page, i.e. nothing (measured: "12.6 GB in 1 ms").
     auto touch = [=](size_t lo, size_t hi) {
         char* p = static_cast<char*>(buf);
-        for (size_t o = lo; o < hi; o += page) (void)__atomic_fetch_or(p + o, (char)0, __ATOMIC_RELAXED);
-        if (hi > lo) (void)__atomic_fetch_or(p + hi - 1, (char)0, __ATOMIC_RELAXED);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p + lo), b = reinterpret_cast<uintptr_t>(p + hi);
+        const uintptr_t pa = (a + page - 1) & ~(uintptr_t)(page - 1), pb = b & ~(uintptr_t)(page - 1);
+        bool populated = false;
+#ifdef MADV_POPULATE_WRITE
+        if (pb > pa) populated = madvise(reinterpret_cast<void*>(pa), pb - pa, MADV_POPULATE_WRITE) == 0;
+#else
+        if (pb > pa) populated = madvise(reinterpret_cast<void*>(pa), pb - pa, 23) == 0;
+#endif
+        auto poke = [](char* q) { __asm__ __volatile__("lock; orb $0, (%0)" : : "r"(q) : "memory", "cc"); };
+        if (!populated)
+            for (size_t o = lo; o < hi; o += page) poke(p + o);
+        if (hi > lo) { poke(p + lo); poke(p + hi - 1); }                 // the partial pages at either end
     };
     if (nt == 1) { touch(0, bytes); return GF_OK; }
     std::vector<std::thread> th;

@@ -29,9 +29,9 @@ def empty_for_download(shape, dtype=np.float64, copier_maps_pages=False):
 class Prefaulted:
     """A result array allocated AHEAD of the device work that fills it, its pages mapped by a background thread
     (gf_host_prepare releases the GIL) while the GPU is busy with that work -- a grid scan knows the size of its result
-    before the burn-in starts, and the host has nothing else to do until the chain is ready.  The mapping does not change
-    the content and may overlap the copy that fills the array (an atomic OR with zero per page): `array` can be handed to
-    the copy at once; `get()` / `finish()` join the thread."""
+    once the burn-in is enqueued, and the host has nothing else to do until the chain is ready.  The mapping does not change
+    the content (madvise(MADV_POPULATE_WRITE)); `get()` / `finish()` join the thread -- do that before launching or allocating
+    anything: page-faulting threads hold those calls up."""
 
     def __init__(self, shape, dtype=np.float64, threads=0):
         import threading

@@ -197,9 +197,14 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed,
                                                    stream_ids=order)
         sampler.on_nonunitary = "-inf"
+        # burn-in: enqueued, and only then -- while the GPU works through it and this thread has nothing to launch or allocate --
+        # the result array is allocated and its pages are mapped (the size is known; model.Prefaulted).  Many threads taking page
+        # faults hold up this thread's launches and allocations (they share the address space's lock), so the mapping must not
+        # run beside them: it is waited for before the stored run starts (gather.destination)
+        sampler.run_async(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
         if gather is not None:
-            gather.prepare(first, len(order), len(points), nsteps)  # the result array: its pages are mapped while the GPU burns in
-        sampler.run_mcmc(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
+            gather.prepare(first, len(order), len(points), nsteps)
+        sampler.wait()
         sampler.reset()
         streamed = None
         if gather is not None and gather.streams_chain(first):
@@ -270,42 +275,36 @@ class DeviceGather:
         self._dest = None
 
     def prepare(self, first_job, n_local, n_points, nsteps):
-        """Allocate the array the gathered chains will land in -- its size is known before the first step -- and have its
-        pages mapped in the background while the GPU samples (model.Prefaulted).  Only where this rank receives anything."""
+        """Hook for allocating the result array ahead of the run and mapping its pages in the background (model.Prefaulted,
+        GF_SCAN_PREFAULT=1).  OFF by default: measured on the MI355X boxes with the pages REALLY mapped
+        (madvise(MADV_POPULATE_WRITE); an earlier version's atomic OR with zero had been compiled into a load, which maps
+        nothing) every variant lost -- beside the run (page-faulting threads hold up this thread's launches and allocations),
+        and also confined to the burn-in and waited for (C5 100 + 200: 0.166-0.179 s against 0.122-0.126 s; at the reference's
+        length 0.67-0.69 s against 0.38-0.52 s): the copy threads of the read-back map the pages they write as they go, on
+        the cores that use them, and that is the fastest arrangement found (profiles/r03/readback.txt)."""
+        if not os.environ.get("GF_SCAN_PREFAULT"):
+            return
         per = nsteps * first_job.nwalkers
         width = first_job.ndim if first_job.post_model is None else 3 + first_job.ndim
-        if os.environ.get("GF_SCAN_NO_PREFAULT"):                 # A/B: the callee allocates when it needs the array
-            return
-        threads = 0
         if self.streams_chain(first_job):
             shape = (n_local, nsteps, first_job.nwalkers, first_job.ndim)
         elif self.rccl is not None and self.rank == self.root:
             shape = (self.world, gdist.slots_per_rank(n_points, self.world), per, width)
-        elif self.rccl is None and self.world == 1:
-            # one rank with post-processing (C4): the sampling takes 7-20 ms and is followed by allocations and many launches, all
-            # of which sixteen page-faulting threads hold up (measured: a net loss); TWO threads run ahead of the read-back without
-            # getting in the way: c4_scan 0.084 -> 0.066 s (profiles/r03/readback.txt)
-            shape, threads = (n_local, per, width), 2
         else:
-            return
-        self._dest = Prefaulted(shape, threads=threads)
+            shape = (n_local, per, width)
+        self._dest = Prefaulted(shape)
 
     def destination(self, shape):
-        """The prepared array if it has this shape (else None: the callee allocates).  Its pages may still be being mapped: the
-        copy that fills it may start at once (model.Prefaulted); `finish_destination` waits for the mapping thread."""
+        """The prepared array, its pages mapped (waits for the mapping threads), if it has this shape (else None: the callee
+        allocates)."""
         d, self._dest = self._dest, None
         if d is None:
             return None
-        if d.array.shape != tuple(shape):
-            d.finish()
-            return None
-        self._mapping = d
-        return d.array
+        a = d.get()
+        return a if a.shape == tuple(shape) else None
 
     def finish_destination(self):
-        d, self._mapping = getattr(self, "_mapping", None), None
-        if d is not None:
-            d.finish()
+        pass
 
     def _exchange(self, d_send, nbytes, shape, dtype):
         if self.rccl is None:

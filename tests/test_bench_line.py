@@ -163,10 +163,11 @@ class _Job:
 
 
 @pytest.mark.parametrize("n_points,world,with_rows", [(5, 2, False), (7, 3, True), (4, 3, False), (8, 2, True), (3, 3, False), (9, 4, True)])
-def test_device_gather_packing_and_indexing_with_a_fake_rccl(n_points, world, with_rows):
+def test_device_gather_packing_and_indexing_with_a_fake_rccl(n_points, world, with_rows, monkeypatch):
     """Grid point g must come back from slot [g mod world, g div world] whatever the grid / world sizes: grids that do not
     divide evenly, ranks with fewer points than slots.  (A rank with NO point never reaches the gather: scan.main and
     bench.py use the device gather only when there are at least as many grid points as ranks.)"""
+    monkeypatch.setenv("GF_SCAN_PREFAULT", "1")
     nstored, nw, ndim = 3, 4, 2
     shared, barrier = [None] * world, threading.Barrier(world)
     results, stats, errors = [None] * world, [None] * world, []
@@ -177,8 +178,8 @@ def test_device_gather_packing_and_indexing_with_a_fake_rccl(n_points, world, wi
             jobs = {g: _Job(nw, ndim, object() if with_rows else None) for g in order}
             g = scan.DeviceGather(_FakeRccl(rank, world, shared, barrier), rank, world, _FakeModel())
             if n_points % 2:                                       # with and without the result array allocated ahead of the run
-                g.prepare(jobs[order[0]], len(order), n_points, nstored)
-                assert (g._dest is not None) == (rank == 0)        # only the root receives anything
+                g.prepare(jobs[order[0]], len(order), n_points, nstored)     # (opt-in: GF_SCAN_PREFAULT, set by the test below)
+                assert g._dest is not None
             results[rank] = g.run(_FakeSampler(order, nstored, nw, ndim, with_rows), jobs, order, n_points)
             stats[rank] = dict(g.stats)
         except Exception as exc:           # noqa: BLE001
