@@ -190,7 +190,7 @@ int gf_flavor_histogram_device(gf_model* m, const double* d_fr, int64_t n, int n
 int gf_flavor_histogram(gf_model* m, const double* fr, int64_t n, int nbins, uint64_t* counts);
 int gf_model_sync(gf_model* m);
 /* Touch the pages of a freshly allocated host buffer from several threads (the content is preserved, and a copy may be filling
- * the buffer at the same time: the touch is an atomic OR with zero), so that a following
+ * the buffer at the same time: madvise(MADV_POPULATE_WRITE), or a locked OR of zero per page where the kernel lacks it), so that a following
  * large device-to-host copy (gf_sampler_get_chain: sampler.chain of golemflavor/mcmc.py:43) runs at PCIe speed instead of
  * page-fault speed.  (gf_memcpy_d2h and gf_sampler_postprocess_rows do not need it: their staging threads map the pages.) */
 int gf_host_prepare(void* buf, size_t bytes);
