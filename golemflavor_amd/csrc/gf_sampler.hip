@@ -844,8 +844,6 @@ void mark_block(gf_sampler* s, hipStream_t st, int64_t nstored)
         delete[] s->mark_events; delete[] s->mark_nstored;
         s->mark_events = ev; s->mark_nstored = ns; s->mark_cap = cap;
     }
-    static const bool trace = std::getenv("GF_TRACE_MARKS") != nullptr;
-    if (trace) std::fprintf(stderr, "mark %d at %lld stored steps\n", s->nmarks, (long long)nstored);
     hipEvent_t& e = s->mark_events[s->nmarks];
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); return; }
     if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); return; }
