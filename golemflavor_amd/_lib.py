@@ -158,10 +158,12 @@ def check(code, what=""):
 
 
 def diagnostic_overrides():
-    """The GF_* environment overrides the library has honoured in this process ('' = none)."""
+    """The GF_* environment overrides honoured in this process ('' = none): the library's own list, plus the host side's A/B
+    switches of the grid scans (GF_SCAN_*), which change how a scan is scheduled, never what it computes."""
     buf = C.create_string_buffer(1100)
     check(lib().gf_diagnostic_overrides(buf, 1100), "gf_diagnostic_overrides")
-    return buf.value.decode()
+    host = " ".join("%s=%s" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith("GF_SCAN_"))
+    return (buf.value.decode() + " " + host).strip()
 
 
 def device_trim(device=0):
