@@ -732,8 +732,9 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const G
     }
 }
 
-// The device sampler's parked proposals (gf_sampler.hip, gf_launch.h GfSettleArgs): the same three-lane arbitration, and at
-// the end of a walker -- one bin failed, or all of them passed -- lane 0 of the group completes that walker's half-step exactly
+// The device sampler's parked proposals (gf_sampler.hip, gf_launch.h GfSettleArgs): the same arbitration (on the nine-lane team:
+// the half-step waits for this kernel), and at the end of a walker -- one bin failed, or all of them passed -- the group's leading
+// lane completes that walker's half-step exactly
 // as the half-step kernel does for the proposals it settles itself: a proposal the reference would have raised on is rejected
 // and counted, any other goes through the accept test ln(z^(ndim-1) / u) > lnp(s) - lnp(q); the stored sample is written.
 #ifdef GF_SETTLE_TIMING
