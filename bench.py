@@ -317,7 +317,10 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
         stage.close()
         local = dict(scan.PHASES)
         local.update({k: v for k, v in g.stats.items() if isinstance(v, (int, float)) and k not in ("ranks", "slots_per_rank")})
-        gather_kind = "rccl gather to rank 0 over xGMI (gf_comm_gather), one download" if rccl is not None else "device -> host (one rank)"
+        gather_kind = "device -> host (one rank)"
+        if rccl is not None:
+            gather_kind = ("rccl gather to rank 0 over xGMI (gf_comm_gather), one download" if getattr(rccl, "kind", "rccl") == "rccl" else
+                           "hipIpc gather to rank 0, device to device (gf_ipc_gather: RCCL unavailable), one download")
         if g.stats.get("note"):
             gather_kind += ": " + g.stats["note"]
     else:
@@ -415,7 +418,7 @@ def load_traffic(n):
 
 
 def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_ms, control_plane, librccl, traffic=None,
-                  traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None,
+                  traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None, device_gather=None,
                   overrides=""):
     """The ONE JSON line, from plain numbers (no GPU, no library: tests/test_bench_line.py).  `elapsed`, `kernel_ms`: already
     reduced over the ranks (reduce_step_timing).  `extras`: sub-records by key.  `cpu`: the cpu_baseline record."""
@@ -451,6 +454,8 @@ def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_m
         out["rccl_init_s"] = rccl_init_s
     if gathered_ok is not None:
         out["rccl_gather_ok"] = gathered_ok
+    if device_gather is not None:
+        out["device_gather"] = device_gather          # "rccl" | "hipIpc": the path the chain blocks took between the ranks' GPUs
     if rccl_error is not None:
         out["rccl_error"] = rccl_error
     for key, rec in (extras or {}).items():
@@ -485,11 +490,13 @@ def main():
         # region has no collective, so an RCCL problem must not cost the measurement: the descriptor then goes over the
         # control plane, the failure is reported in the JSON line AND in the exit status.
         t_r = time.perf_counter()
-        rccl, rccl_error, stuck = gdist.open_rccl(rank, world, local_rank, control,
-                                                  timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+        # (open_device_gather: where the communicator cannot be set up and the ranks share a node, the chain blocks still go
+        # device to device, through hipIpc; `rccl.kind` says which)
+        rccl, rccl_error, stuck = gdist.open_device_gather(rank, world, local_rank, control,
+                                                           timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
         rccl_init_s = float(control.allreduce_max([time.perf_counter() - t_r])[0])
         # fixed physics constants: rank 0's packed descriptor is the one everybody uses
-        desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if rccl is not None else control)[0]
+        desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if getattr(rccl, "kind", None) == "rccl" else control)[0]
 
     n = a.walkers * a.ensembles
     model = Model(desc, device=local_rank)
@@ -587,6 +594,7 @@ def main():
                             control_plane="tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
                             librccl=gdist.rccl_library_info(), traffic=traffic, traffic_src=traffic_src,
                             gathered_ok=gathered_ok, rccl_error=rccl_error, rccl_init_s=rccl_init_s, extras=extras, cpu=cb,
+                            device_gather=getattr(rccl, "kind", None),
                             parity=parity, overrides=_lib.diagnostic_overrides())
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

@@ -14,6 +14,7 @@ GF_ABI_VERSION = 3
 GF_MAX_DIM = 16
 GF_MAX_BINS = 64
 GF_COMM_ID_BYTES = 128
+GF_IPC_HANDLE_BYTES = 64
 
 GF_OK, GF_ERR_INVALID_ARG, GF_ERR_NO_DEVICE, GF_ERR_HIP, GF_ERR_ALLOC, GF_ERR_COMM, GF_ERR_UNSUPPORTED, GF_ERR_QUEUE_OVERFLOW = range(8)
 GF_ST_OK, GF_ST_OUT_OF_PRIOR, GF_ST_NON_UNITARY, GF_ST_NAN = range(4)
@@ -106,6 +107,8 @@ SIGNATURES = {
     "gf_comm_broadcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "gf_comm_allgather": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gf_comm_gather": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
+    "gf_ipc_export": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "gf_ipc_gather": (C.c_int, [C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
     "gf_comm_barrier": (C.c_int, [_vp]),
     "gf_comm_last_error": (C.c_char_p, []),
     "gf_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t]),

@@ -195,4 +195,52 @@ int gf_comm_barrier(gf_comm* c)
     return GF_OK;
 }
 
+// ---- the same gather without RCCL: device memory shared between the processes of ONE node (hipIpc) -----------------------------
+// Fallback for a node where the RCCL communicator cannot be set up (and the only inter-process device path that can be
+// exercised on a one-GPU box: RCCL refuses two ranks on one device, hipIpc does not).  Every rank exports a handle of its
+// block (gf_ipc_export: 64 bytes, shipped over the control plane); the root opens the handles and copies the blocks into its
+// receive buffer device to device -- over xGMI when the ranks sit on different GPUs (peer access is enabled lazily by the
+// open) -- then closes them.  The senders keep their blocks alive until the root reports back (the caller's barrier).
+int gf_ipc_export(const void* d_ptr, unsigned char* handle64)
+{
+    if (!d_ptr || !handle64) return GF_ERR_INVALID_ARG;
+    static_assert(sizeof(hipIpcMemHandle_t) == GF_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    GF_CHIP(hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)));
+    std::memcpy(handle64, &h, sizeof(h));
+    return GF_OK;
+}
+
+int gf_ipc_gather(int device, const unsigned char* handles, int nranks, int self_rank, const void* d_own, void* d_recv,
+                  size_t bytes_per_rank)
+{
+    if (!handles || nranks < 1 || self_rank < 0 || self_rank >= nranks || !d_own || !d_recv) return GF_ERR_INVALID_ARG;
+    if (bytes_per_rank == 0) return GF_OK;
+    GF_CHIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    GF_CHIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    char* dst = static_cast<char*>(d_recv);
+    void* opened[64] = {};
+    hipError_t e = hipSuccess;
+    if (nranks > 64) e = hipErrorInvalidValue;
+    for (int r = 0; r < nranks && e == hipSuccess; ++r) {
+        if (r == self_rank) {
+            if (dst + (size_t)r * bytes_per_rank != d_own)
+                e = hipMemcpyAsync(dst + (size_t)r * bytes_per_rank, d_own, bytes_per_rank, hipMemcpyDeviceToDevice, st);
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * GF_IPC_HANDLE_BYTES, sizeof(h));
+        e = hipIpcOpenMemHandle(&opened[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst + (size_t)r * bytes_per_rank, opened[r], bytes_per_rank, hipMemcpyDefault, st);
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    for (int r = 0; r < nranks && r < 64; ++r)
+        if (opened[r]) (void)hipIpcCloseMemHandle(opened[r]);
+    (void)hipStreamDestroy(st);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return comm_fail("gf_ipc_gather", hipGetErrorString(e));
+    return GF_OK;
+}
+
 }  // extern "C"

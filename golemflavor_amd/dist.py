@@ -292,6 +292,8 @@ class RcclBackend:
     no id yet, `control` does the exchange here: the backend that ships it (SocketBackend / GlooBackend), or a callable
     `exchange_id(id_bytes_or_None) -> id_bytes`."""
 
+    kind = "rccl"
+
     def __init__(self, rank, world, device, control=None, uid=None):
         self._L = _lib.lib()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
@@ -340,6 +342,66 @@ class RcclBackend:
         if getattr(self, "_h", None) is not None:
             self._L.gf_comm_destroy(self._h)
             self._h = None
+
+
+class IpcBackend:
+    """The device gather without RCCL, for ranks on ONE node: blocks are shared between the processes as hipIpc handles
+    (gf_ipc_export / gf_ipc_gather; 64 bytes each over `control`), the root copies them device to device.  Same
+    `gather_device` face as RcclBackend, so `scan.DeviceGather` takes either.  The fallback when the RCCL communicator
+    cannot be set up (`open_device_gather`), and the only inter-process DEVICE path a one-GPU box can exercise (RCCL refuses
+    two ranks on one device): tests/test_gpu_mcmc.py runs a two-rank scan over it."""
+
+    kind = "hipIpc"
+
+    def __init__(self, rank, world, device, control):
+        self._L = _lib.lib()
+        self.rank, self.world, self.device, self.control = int(rank), int(world), int(device), control
+        self.init_seconds = 0.0
+
+    def gather_device(self, d_send, d_recv_on_root, bytes_per_rank, root=0):
+        h = (C.c_uint8 * _lib.GF_IPC_HANDLE_BYTES)()
+        _lib.check(self._L.gf_ipc_export(d_send, h), "gf_ipc_export")
+        blobs = self.control.gather_bytes(bytes(h), root)
+        err = b""
+        if self.rank == root:
+            try:
+                allh = (C.c_uint8 * (_lib.GF_IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(blobs))
+                _lib.check(self._L.gf_ipc_gather(self.device, allh, self.world, self.rank, d_send, d_recv_on_root, int(bytes_per_rank)),
+                           "gf_ipc_gather")
+            except Exception as exc:       # noqa: BLE001  -- the senders are waiting: tell them before raising
+                err = ("%s: %s" % (type(exc).__name__, exc)).encode()
+        # the senders keep their blocks until the root is done; the root's outcome reaches everybody
+        err = self.control.broadcast_bytes(err, root)
+        if err:
+            raise _lib.GolemHipError(_lib.GF_ERR_COMM, "ipc gather failed on rank %d: %s" % (root, err.decode()))
+
+    def barrier(self):
+        self.control.barrier()
+
+    def close(self):
+        pass
+
+
+def same_node(control):
+    """True when every rank of `control` runs on this host (hipIpc handles mean nothing elsewhere)."""
+    import socket
+    names = control.allgather_bytes(socket.gethostname().encode())
+    return all(n == names[0] for n in names)
+
+
+def open_device_gather(rank, world, device, control, timeout=120.0):
+    """The device-to-device gather of a scan: RCCL if its communicator comes up (`open_rccl`), else -- the ranks being on one
+    node -- hipIpc.  Returns (backend or None, rccl error or None, stuck): the RCCL error is reported whatever the fallback
+    did; `backend.kind` says which path the chains will take."""
+    b, err, stuck = open_rccl(rank, world, device, control, timeout=timeout)
+    if b is not None or stuck or world < 2:
+        return b, err, stuck
+    try:
+        if same_node(control):
+            return IpcBackend(rank, world, device, control), err, False
+    except Exception:                      # noqa: BLE001
+        pass
+    return None, err, False
 
 
 def rccl_library_info():

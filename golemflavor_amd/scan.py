@@ -420,11 +420,12 @@ def main(argv=None):
         make = lambda p, g: _SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
         evals_per_point = nw * (a.burnin + a.nsteps)
     mine = gdist.shard(len(pts), rank, world)
-    # chain blocks travel over RCCL / xGMI, device buffer to device buffer; if the communicator cannot be set up the
-    # blocks go through the host control plane instead and the failure is reported
+    # chain blocks travel over RCCL / xGMI, device buffer to device buffer; if the communicator cannot be set up they are shared
+    # between the node's processes through hipIpc (still device to device), and failing that go through the host control
+    # plane; the RCCL failure is reported either way
     rccl, rccl_err, stuck = None, None, False
     if world > 1 or os.environ.get("GF_SCAN_RCCL"):
-        rccl, rccl_err, stuck = gdist.open_rccl(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+        rccl, rccl_err, stuck = gdist.open_device_gather(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
     stacked = not a.no_stack
     device_gather = stacked and not a.datadir and (rccl is not None or world == 1) and len(pts) >= world
     if device_gather:
@@ -448,7 +449,7 @@ def main(argv=None):
             mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
                           "nsteps": a.nsteps, "stacked": stacked,
-                          "gather": ("rccl device gather to rank 0" if rccl is not None else "device -> host") if device_gather
+                          "gather": (("%s device gather to rank 0" % rccl.kind) if rccl is not None else "device -> host") if device_gather
                           else ("socket control plane" if world > 1 else "local"),
                           "rccl_error": rccl_err, "librccl": gdist.rccl_library_info(),
                           "diagnostic_overrides": _lib.diagnostic_overrides(),

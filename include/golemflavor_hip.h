@@ -286,6 +286,15 @@ int gf_comm_allgather(gf_comm* c, const void* d_send, void* d_recv, size_t bytes
  * root holds nranks x the block.  Stands in for the reference's N jobs saving N chain files to one place
  * (golemflavor/mcmc.py:108-126, submitter/mc_texture_dag.py:57-71): one ncclGroup of point-to-point transfers into the root. */
 int gf_comm_gather(gf_comm* c, const void* d_send, void* d_recv_on_root, size_t bytes_per_rank, int root);
+/* ABI 3.  The same gather without a communicator, for the ranks of ONE node: gf_ipc_export turns a rank's block (the base of a
+ * gf_device_alloc'd buffer) into a 64-byte handle that travels over the caller's control plane; on the root gf_ipc_gather opens the
+ * nranks handles (its own slot is ignored: d_own is copied), copies every block to d_recv + r * bytes_per_rank device to device --
+ * over xGMI between GPUs -- and closes them.  The senders must keep their blocks until the root has returned (a barrier of the
+ * control plane).  Fallback where RCCL cannot be set up; also the one inter-process device path a one-GPU box can exercise. */
+#define GF_IPC_HANDLE_BYTES 64
+int gf_ipc_export(const void* d_ptr, unsigned char* handle64);
+int gf_ipc_gather(int device, const unsigned char* handles, int nranks, int self_rank, const void* d_own, void* d_recv,
+                  size_t bytes_per_rank);
 int gf_comm_barrier(gf_comm* c);
 const char* gf_comm_last_error(void);                 /* thread-local text of the last failing gf_comm_* call */
 int gf_comm_library_info(char* buf, size_t buflen);   /* "<ncclGetVersion code> <path of the loaded librccl>" */

@@ -217,6 +217,40 @@ def test_scan_gathers_over_rccl_between_two_gpus(config, tmp_path, capsys):
     assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("config,world", [("C4", 2), ("C5", 2), ("C5", 3)])
+def test_scan_gathers_between_processes_on_one_gpu_over_hipipc(config, world, tmp_path, capsys):
+    """The N > 1 DEVICE data path on the hardware this suite always has: `world` ranks in separate processes on ONE GPU.  RCCL
+    refuses more than one rank per device (the error is reported and the exit status is 3, as designed), so the chain blocks
+    take the fallback of `dist.open_device_gather`: shared between the processes as hipIpc handles over the socket control
+    plane and copied device to device by rank 0 (gf_ipc_export / gf_ipc_gather), then downloaded once -- scan.DeviceGather's
+    packing, slot mapping (5 grid points: ragged over 2 and 3 ranks) and root-only receive buffer with real device buffers.
+    The result must be the single-rank scan's, bit for bit."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from golemflavor_amd import scan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scan.main(["--config", config, "--points", "5", "--nwalkers", "32", "--burnin", "6", "--nsteps", "9", "--outfile", str(tmp_path / "one")])
+    capsys.readouterr()
+    script = tmp_path / "child.py"
+    script.write_text(_TWO_RANK_CHILD)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", GF_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GF_RCCL_TIMEOUT="30", PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "many"), config], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 3 for p in procs), [(p.returncode, o[1][-1500:]) for p, o in zip(procs, outs)]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["ranks"] == world and line["gather"] == "hipIpc device gather to rank 0" and "ncclCommInitRank" in line["rccl_error"]
+    assert line["gather_stats"]["gather_bytes"] > 0 and line["gather_stats"]["ranks"] == world
+    a, b = np.load(str(tmp_path / "one.npy")), np.load(str(tmp_path / "many.npy"))
+    assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
 def test_scan_rows_to_host_equal_rows_on_device():
     """gf_sampler_postprocess_rows hands the scan's rows to the host group by group while later chains are still being
     post-processed; they must be the rows gf_sampler_postprocess_rows_device assembles (19 chains: ragged last group)."""
