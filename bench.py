@@ -102,20 +102,37 @@ def synth_theta(ps, n, seed):
 
 
 def cpu_baseline(ps, bf, theta, sample):
-    """Time the CPU oracle (checker, never the product) on a bounded sample of the same workload."""
+    """Time the CPU oracle (checker, never the product) on a bounded sample of the same workload: with the 16 threads of a
+    per-GPU share of this host (what rounds 1-3 reported) AND with every core this process may run on
+    (`len(os.sched_getaffinity(0))`); `value` / `cores` are the LARGER configuration's, so `gpu_over_cpu` is against the whole
+    host the box grants, and the other figure stays in the record."""
     from oracle import oracle as O
     om = O.make_model(ps, "SM_GAUSS", bestfit_fr=bf, smearing=0.02)
-    cores = min(os.cpu_count() or 1, 16)   # the GPU box grants a 16-core share per GPU
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:                      # pragma: no cover
+        allowed = os.cpu_count() or 1
+    share = min(allowed, 16)                  # a 16-core share per GPU: the figure of rounds 1-3
     th1 = theta[:min(len(theta), 200000)]
     t0 = time.perf_counter()
     O.lnprob_batch(om, th1)
     t1 = time.perf_counter() - t0
     rate1 = len(th1) / t1
-    n = sample or int(min(len(theta), max(200000, rate1 * cores * 8.0)))   # ~8 s of all-core work
-    ths = theta[:n]
-    t0 = time.perf_counter()
-    ref = O.lnprob_batch(om, ths, threads=cores)
-    tm = time.perf_counter() - t0
+    runs = []
+    ref = None
+    for cores in sorted({share, allowed}):
+        n = sample or int(min(len(theta), max(200000, rate1 * cores * 4.0)))   # one pass: ~4 s of work at perfect scaling ...
+        ths = theta[:n]
+        passes, tm = 0, 0.0
+        while passes == 0 or (tm < 3.0 and passes < 64 and not sample):        # ... repeated until 3 s have been timed
+            t0 = time.perf_counter()
+            out = O.lnprob_batch(om, ths, threads=cores)
+            tm += time.perf_counter() - t0
+            passes += 1
+        runs.append({"cores": cores, "value": n * passes / tm, "evaluations": n * passes, "seconds": tm, "passes": passes})
+        if ref is None or len(out) > len(ref):
+            ref = out
+    best = max(runs, key=lambda r: r["value"])
     # the Python reference itself never travels to the GPU box; its rate was measured in the build
     # container when the golden vectors were generated (tests/golden/golden_meta.json, 1 core)
     ref_rate = None
@@ -124,12 +141,14 @@ def cpu_baseline(ps, bf, theta, sample):
         ref_rate = 1e6 / meta["timings"]["notebook_ln_prob_us"]
     except Exception:
         pass
-    return {"value": n / tm, "unit": "evals/s", "cores": cores, "kind": "port",
+    return {"value": best["value"], "unit": "evals/s", "cores": best["cores"], "kind": "port",
             "sample": "%d evaluations of the bench theta batch, oracle/golem_oracle.c (long double), %d threads; "
-                      "single-thread rate %.3g evals/s on %d evaluations" % (n, cores, rate1, len(th1)),
-            "single_thread_value": rate1,
+                      "single-thread rate %.3g evals/s on %d evaluations" % (best["evaluations"], best["cores"], rate1, len(th1)),
+            "single_thread_value": rate1, "cores_allowed": allowed, "host_cpus": os.cpu_count(),
+            "by_cores": runs,
             "reference_python_evals_per_s_1core_build_container": ref_rate,
-            "note": "the reference's own rate was timed in the build container (another machine): "
+            "note": "value = the faster of the two thread counts tried (a 16-core share, and every core this process may use); "
+                    "the reference's own rate was timed in the build container (another machine): "
                     "gpu_over_reference_python_1core compares across machines"}, ref
 
 
@@ -287,7 +306,7 @@ def scan_record_from_phases(config, world, n_points, walkers, burnin, nsteps, ev
            "rccl_init_s": rccl_init_s, "setup_s": phases.get("setup"), "sampling_s": phases.get("sampling"),
            "pack_s": phases.get("pack_s"), "xgmi_s": xgmi_s, "gather_bytes": int(gbytes),
            "gather_GBps": (gbytes / xgmi_s / 1e9) if (xgmi_s and gbytes) else None,
-           "d2h_s": phases.get("d2h_s"), "gather": gather_kind,
+           "d2h_s": phases.get("d2h_s"), "d2h_bytes": int(phases.get("d2h_bytes", 0.0)), "gather": gather_kind,
            "sampling_evals_per_s": n_points * walkers * (burnin + nsteps) / max(phases.get("sampling") or seconds, 1e-12),
            "phases": {k: round(v, 4) for k, v in phases.items() if not k.endswith("_bytes")}}
     if chain_bytes_to_host is not None:
@@ -299,20 +318,83 @@ def scan_record_from_phases(config, world, n_points, walkers, burnin, nsteps, ev
     return rec
 
 
-def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rccl=None, rccl_init_s=None):
-    """C4 / C5 end to end at full size, the grid sharded over the ranks: stacked device sampler, post-processing (C4), chains
-    gathered to rank 0 (RCCL / xGMI, then one download) -- golemflavor_amd.scan's own code path.  EVERY rank calls this;
-    rank 0 gets the record, the others None."""
+def device_gather_subphase(rccl, device, region, whole, rank, world, control):
+    """The device-resident gather `north_star` names, as its OWN sub-phase (never part of a scan's `seconds`): every rank's
+    block -- the bytes it has just delivered to the host segment, uploaded again -- goes GPU to GPU onto rank 0
+    (`gf_comm_gather` over RCCL / xGMI, or hipIpc), timed barrier to barrier, and rank 0 checks what arrived against the
+    segment (head and tail of every rank's block, bit patterns).  Every rank calls this; rank 0 gets the record."""
+    nbytes = int(region.nbytes)
+    rec = {"kind": getattr(rccl, "kind", "rccl"), "bytes_per_rank": nbytes, "bytes_into_root": nbytes * (world - 1), "ranks": world}
+    err = ""
+    stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
+    d_send = d_recv = None
+    try:
+        d_send = stage.alloc(nbytes).upload(np.ascontiguousarray(region))
+        d_recv = stage.alloc(nbytes * world) if rank == 0 else None
+    except Exception as exc:               # noqa: BLE001
+        err = "%s: %s" % (type(exc).__name__, exc)
+    errs = control.allgather_bytes(err.encode())        # nobody enters the gather unless everybody can
+    err = next((e.decode() for e in errs if e), "")
+    dt = 0.0
+    if not err:
+        control.barrier()
+        t0 = time.perf_counter()
+        try:
+            rccl.gather_device(d_send.ptr, d_recv.ptr if rank == 0 else None, nbytes, 0)
+        except Exception as exc:           # noqa: BLE001
+            err = "%s: %s" % (type(exc).__name__, exc)
+        dt = time.perf_counter() - t0
+    dt = float(control.allreduce_max([dt])[0])
+    errs = control.allgather_bytes(err.encode())
+    err = next((e.decode() for e in errs if e), "")
+    if rank == 0 and not err:
+        piece = min(nbytes, 4 << 20) // 8 * 8
+        ok = True
+        for r in range(world):
+            want = whole[r].reshape(-1).view(np.uint64)
+            for off in sorted({0, nbytes - piece}):
+                got = d_recv.download((piece // 8,), dtype=np.uint64, offset_bytes=r * nbytes + off)
+                ok = ok and bool(np.array_equal(got, want[off // 8: off // 8 + piece // 8]))
+        rec.update(seconds=dt, GBps=(nbytes * (world - 1) / dt / 1e9) if dt > 0 else None, verified=ok,
+                   verified_how="head and tail (%d bytes each) of every rank's block, bit patterns against the host segment" % piece)
+    if err:
+        rec["error"] = err
+    for d in (d_send, d_recv):
+        if d is not None:
+            d.free()
+    stage.close()
+    try:
+        rec["comm_nranks"] = rccl.nranks()
+    except Exception:                      # noqa: BLE001
+        pass
+    return rec if rank == 0 else None
+
+
+def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rccl=None, rccl_init_s=None, shared=False):
+    """C4 / C5 end to end at full size, the grid sharded over the ranks -- golemflavor_amd.scan's own code path: stacked device
+    sampler per rank, post-processing (C4), and the delivery: `shared` (the ranks are on one node): every rank reads its own
+    chains back over its own PCIe link into one host segment rank 0 maps too (scan.SharedHostGather), with the device gather
+    (`gf_comm_gather` over RCCL / xGMI, or hipIpc) measured afterwards as a sub-phase of its own; otherwise the device gather
+    to rank 0 and one download; no communicator: the host control plane.  EVERY rank calls this; rank 0 gets the record, the
+    others None."""
     from golemflavor_amd import scan
     control = control or gdist.LocalBackend()
     pts, nw, make, evals = scan_setup(config, device)
     mine = gdist.shard(len(pts), rank, world)
     control.barrier()
     t0 = time.perf_counter()
-    chains, gather_kind, local = None, None, {}
-    if world == 1 or rccl is not None:
+    chains, gather_kind, local, g = None, None, {}, None
+    if world > 1 and shared:
+        g = scan.SharedHostGather(control, rank, world)
+        chains = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True, gather=g)
+        local = dict(scan.PHASES)
+        local.update({k: v for k, v in g.stats.items() if isinstance(v, (int, float)) and k not in ("ranks", "slots_per_rank")})
+        gather_kind = g.stats.get("delivery", g.kind)
+        if g.stats.get("note"):
+            gather_kind += ": " + g.stats["note"]
+    elif world == 1 or rccl is not None:
         stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
-        g = scan.DeviceGather(rccl, rank, world, stage)
+        g = scan.DeviceGather(rccl, rank, world, stage, control=control)
         chains = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True, gather=g)
         stage.close()
         local = dict(scan.PHASES)
@@ -333,16 +415,34 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
         gather_kind = "host control plane (tcp) -- RCCL unavailable"
     local["rank_seconds"] = time.perf_counter() - t0
     control.barrier()
-    seconds = time.perf_counter() - t0                      # barrier to barrier: the slowest rank, the gather included
+    seconds = time.perf_counter() - t0                      # barrier to barrier: the slowest rank, the delivery included
     phases = reduce_phases(control, local)
     seconds = float(control.allreduce_max([seconds])[0])
+    # every rank's own numbers next to the reductions: how many links carried the result, and how long each was busy
+    per_rank = control.allgather(np.array([local.get("d2h_s", 0.0), local.get("d2h_bytes", 0.0), local.get("sampling", 0.0),
+                                           local["rank_seconds"]], dtype=np.float64))
+    sub = None
+    if world > 1 and shared and rccl is not None and getattr(g, "region", None) is not None and g.stats.get("delivery", "").startswith("shared"):
+        sub = device_gather_subphase(rccl, device, g.region, g._all if rank == 0 else None, rank, world, control)
     if rank != 0:
+        if isinstance(g, scan.SharedHostGather):
+            g.release()
         return None
     nbytes = sum(c.nbytes for c in chains)
-    finite = float(np.mean([np.isfinite(c[:: max(1, len(c) // 4096)]).mean() for c in chains]))
-    return scan_record_from_phases(config, world, len(pts), nw, burnin, nsteps, len(pts) * evals(burnin, nsteps), seconds, phases,
-                                   gather_kind=gather_kind, rccl_init_s=rccl_init_s, chain_bytes_to_host=nbytes,
-                                   finite_fraction=finite, nonunitary=dict(scan.LAST_NONUNITARY) if scan.LAST_NONUNITARY else None)
+    finite = scan.finite_fraction(chains)
+    rec = scan_record_from_phases(config, world, len(pts), nw, burnin, nsteps, len(pts) * evals(burnin, nsteps), seconds, phases,
+                                  gather_kind=gather_kind, rccl_init_s=rccl_init_s, chain_bytes_to_host=nbytes,
+                                  finite_fraction=finite, nonunitary=dict(scan.LAST_NONUNITARY) if scan.LAST_NONUNITARY else None)
+    rec["d2h_links"] = int(np.count_nonzero(per_rank[:, 1] > 0)) if world > 1 else 1
+    rec["d2h_s_per_rank"] = [round(float(x), 4) for x in per_rank[:, 0]]
+    rec["d2h_bytes_per_rank"] = [int(x) for x in per_rank[:, 1]]
+    rec["sampling_s_per_rank"] = [round(float(x), 4) for x in per_rank[:, 2]]
+    rec["seconds_per_rank"] = [round(float(x), 4) for x in per_rank[:, 3]]
+    if sub is not None:
+        rec["device_gather_subphase"] = sub
+    if isinstance(g, scan.SharedHostGather):
+        g.release()
+    return rec
 
 
 def extra_emcee(model, ps, walkers):
@@ -419,7 +519,7 @@ def load_traffic(n):
 
 def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_ms, control_plane, librccl, traffic=None,
                   traffic_src=None, gathered_ok=None, rccl_error=None, rccl_init_s=None, extras=None, cpu=None, parity=None, device_gather=None,
-                  overrides=""):
+                  overrides="", rccl_nranks=None):
     """The ONE JSON line, from plain numbers (no GPU, no library: tests/test_bench_line.py).  `elapsed`, `kernel_ms`: already
     reduced over the ranks (reduce_step_timing).  `extras`: sub-records by key.  `cpu`: the cpu_baseline record."""
     n = walkers * ensembles
@@ -455,7 +555,11 @@ def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_m
     if gathered_ok is not None:
         out["rccl_gather_ok"] = gathered_ok
     if device_gather is not None:
-        out["device_gather"] = device_gather          # "rccl" | "hipIpc": the path the chain blocks took between the ranks' GPUs
+        out["device_gather"] = device_gather          # "rccl" | "hipIpc": the device-to-device path between the ranks' GPUs
+    if rccl_nranks is not None:
+        # ranks the communicator itself reports (ncclCommCount on an RCCL communicator; the world size on the hipIpc stand-in),
+        # one entry per rank: "did RCCL see N ranks?" is answered by this list being [N] * N with device_gather == "rccl"
+        out["rccl_nranks"] = rccl_nranks
     if rccl_error is not None:
         out["rccl_error"] = rccl_error
     for key, rec in (extras or {}).items():
@@ -472,8 +576,26 @@ def assemble_line(*, world, steps, warmup, walkers, ensembles, elapsed, kernel_m
 
 
 def main():
+    """`run`, with the control plane's failures turned into a line: a peer that stops answering (dist.ControlPlaneTimeout after
+    GF_CONTROL_TIMEOUT seconds, well under the driver's limit) or goes away (ConnectionError) ends the job with an `error` in
+    rank 0's JSON line and exit status 4 on every rank that noticed -- not with a run killed at its time limit."""
     a = parse()
     json_out = _claim_stdout()
+    try:
+        run(a, json_out)
+    except (gdist.ControlPlaneTimeout, ConnectionError) as exc:
+        msg = "%s: %s" % (type(exc).__name__, exc)
+        sys.stderr.write("bench.py: control plane failure on rank %s: %s\n" % (os.environ.get("RANK", "0"), msg))
+        if int(os.environ.get("RANK", "0")) == 0:
+            json_out.write(json.dumps({"metric": "walker-lnprob evals/sec (Gaussian llh, 100 walkers) at 1/2/4/8 MI355X", "value": None,
+                                       "unit": "evals/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "steps": a.steps,
+                                       "warmup": a.warmup, "error": msg}) + "\n")
+            json_out.flush()
+        sys.stderr.flush()
+        os._exit(4)                        # helper threads (RCCL bootstrap) must not hold the exit
+
+
+def run(a, json_out):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -483,7 +605,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     L = _lib.lib()                           # libgolemhip.so (and with it /opt/rocm's runtime + librccl) before anything else ROCm
     control = gdist.SocketBackend(rank, world) if world > 1 else gdist.LocalBackend()
-    rccl, rccl_error, stuck, rccl_init_s = None, None, False, None
+    rccl, rccl_error, stuck, rccl_init_s, shared = None, None, False, None, False
     ps, bf, desc = notebook_descriptor()
     if world > 1:
         # RCCL communicator of the library itself; its unique id travels over the socket control plane.  The timed
@@ -495,6 +617,8 @@ def main():
         rccl, rccl_error, stuck = gdist.open_device_gather(rank, world, local_rank, control,
                                                            timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
         rccl_init_s = float(control.allreduce_max([time.perf_counter() - t_r])[0])
+        # one node (the contract's case)?  Then the scans deliver over every rank's own PCIe link into one host segment
+        shared = gdist.same_node(control) and not os.environ.get("GF_SCAN_DEVICE_GATHER")
         # fixed physics constants: rank 0's packed descriptor is the one everybody uses
         desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if getattr(rccl, "kind", None) == "rccl" else control)[0]
 
@@ -535,7 +659,7 @@ def main():
     elapsed, kernel_ms = reduce_step_timing(control, elapsed, kernel_ms)
 
     # after the timed region: one chain block (the first ensemble's lnprob) from every rank to rank 0 over RCCL
-    gathered_ok = None
+    gathered_ok, rccl_nranks = None, None
     if rccl is not None:
         try:
             blk = 8 * a.walkers
@@ -551,6 +675,11 @@ def main():
             gathered_ok = False
         oks = control.allgather_bytes(b"1" if gathered_ok else b"0")
         gathered_ok = all(x == b"1" for x in oks)
+        try:                                 # how many ranks the COMMUNICATOR saw (ncclCommCount), as every rank reports it
+            seen = rccl.nranks()
+        except Exception:                  # noqa: BLE001
+            seen = -1
+        rccl_nranks = [int(x) for x in control.allgather(np.array([seen], dtype=np.int64)).reshape(-1)]
 
     # sub-records.  The sharded scans run on EVERY rank (rank 0 assembles); the rest is rank 0's
     extras = {}
@@ -579,7 +708,7 @@ def main():
             guarded("c5_scan", lambda: extra_scan(local_rank, "C5", 100, 200))
         for key, cfg in (("c4_scan_ref", "C4"), ("c5_scan_ref", "C5")):
             guarded(key, lambda cfg=cfg: extra_scan(local_rank, cfg, a.scan_burnin, a.scan_nsteps, rank, world, control, rccl,
-                                                    rccl_init_s), collective=True)
+                                                    rccl_init_s, shared), collective=True)
 
     if rank == 0:
         cb, parity = None, None
@@ -594,7 +723,7 @@ def main():
                             control_plane="tcp sockets (golemflavor_amd.dist.SocketBackend)" if world > 1 else "none (1 rank)",
                             librccl=gdist.rccl_library_info(), traffic=traffic, traffic_src=traffic_src,
                             gathered_ok=gathered_ok, rccl_error=rccl_error, rccl_init_s=rccl_init_s, extras=extras, cpu=cb,
-                            device_gather=getattr(rccl, "kind", None),
+                            device_gather=getattr(rccl, "kind", None), rccl_nranks=rccl_nranks,
                             parity=parity, overrides=_lib.diagnostic_overrides())
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

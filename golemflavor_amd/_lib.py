@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOLEMHIP_LIB") or os.path.join(HERE, "libgolemhip.so")   # override: kernel A/B experiments
 
-GF_ABI_VERSION = 3
+GF_ABI_VERSION = 4
 GF_MAX_DIM = 16
 GF_MAX_BINS = 64
 GF_COMM_ID_BYTES = 128
@@ -110,6 +110,9 @@ SIGNATURES = {
     "gf_ipc_export": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "gf_ipc_gather": (C.c_int, [C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
     "gf_comm_barrier": (C.c_int, [_vp]),
+    "gf_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gf_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    "gf_device_release": (C.c_int, [C.c_int, _vp]),
     "gf_comm_last_error": (C.c_char_p, []),
     "gf_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "gf_host_prepare": (C.c_int, [_vp, C.c_size_t]),

@@ -1435,12 +1435,21 @@ int gf_host_prepare_n(void* buf, size_t bytes, int threads)
         const uintptr_t a = reinterpret_cast<uintptr_t>(p + lo), b = reinterpret_cast<uintptr_t>(p + hi);
         const uintptr_t pa = (a + page - 1) & ~(uintptr_t)(page - 1), pb = b & ~(uintptr_t)(page - 1);
         bool populated = false;
-#ifdef MADV_POPULATE_WRITE
-        if (pb > pa) populated = madvise(reinterpret_cast<void*>(pa), pb - pa, MADV_POPULATE_WRITE) == 0;
-#else
-        if (pb > pa) populated = madvise(reinterpret_cast<void*>(pa), pb - pa, 23) == 0;
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23          /* linux/mman.h, Linux 5.14+; older headers lack the name, older kernels answer EINVAL */
 #endif
+        static const bool force_poke = gf_internal_env("GF_PREPARE_FORCE_POKE", 0) != nullptr;       // tests: the path taken where madvise is refused
+        if (pb > pa && !force_poke) populated = madvise(reinterpret_cast<void*>(pa), pb - pa, MADV_POPULATE_WRITE) == 0;
+        // (x86-64: a locked OR written in assembly -- the compiler turns __atomic_fetch_or(p, 0) into a LOAD there; elsewhere a
+        // compare-and-swap of the byte with itself, which no compiler may drop: it is a write whenever it succeeds)
+#if defined(__x86_64__)
         auto poke = [](char* q) { __asm__ __volatile__("lock; orb $0, (%0)" : : "r"(q) : "memory", "cc"); };
+#else
+        auto poke = [](char* q) {
+            char v = __atomic_load_n(q, __ATOMIC_RELAXED);
+            while (!__atomic_compare_exchange_n(q, &v, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+        };
+#endif
         if (!populated)
             for (size_t o = lo; o < hi; o += page) poke(p + o);
         if (hi > lo) { poke(p + lo); poke(p + hi - 1); }                 // the partial pages at either end

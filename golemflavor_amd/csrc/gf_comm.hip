@@ -195,6 +195,36 @@ int gf_comm_barrier(gf_comm* c)
     return GF_OK;
 }
 
+int gf_comm_info(gf_comm* c, int* nranks, int* rank, int* device)
+{
+    if (!c || !c->comm) return GF_ERR_INVALID_ARG;
+    int n = -1, r = -1, d = -1;
+    GF_NCCL(ncclCommCount(c->comm, &n));
+    GF_NCCL(ncclCommUserRank(c->comm, &r));
+    GF_NCCL(ncclCommCuDevice(c->comm, &d));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
+    return GF_OK;
+}
+
+int gf_device_malloc(int device, size_t bytes, void** dptr)
+{
+    if (!dptr || bytes == 0) return GF_ERR_INVALID_ARG;
+    *dptr = nullptr;
+    GF_CHIP(hipSetDevice(device));
+    GF_CHIP(hipMalloc(dptr, bytes));
+    return GF_OK;
+}
+
+int gf_device_release(int device, void* dptr)
+{
+    if (!dptr) return GF_OK;
+    GF_CHIP(hipSetDevice(device));
+    GF_CHIP(hipFree(dptr));
+    return GF_OK;
+}
+
 // ---- the same gather without RCCL: device memory shared between the processes of ONE node (hipIpc) -----------------------------
 // Fallback for a node where the RCCL communicator cannot be set up (and the only inter-process device path that can be
 // exercised on a one-GPU box: RCCL refuses two ranks on one device, hipIpc does not).  Every rank exports a handle of its

@@ -585,12 +585,23 @@ struct gf_sampler {
     double* graph_lnp_chain = nullptr;
     int64_t graph_cap = -1;
     int graph_has_chain = -1;
-    // gf_sampler_run_to_host: events recorded behind every block of steps of the run in flight, with the number of stored steps
-    // that are final once the event has passed
-    bool marking = false;
-    hipEvent_t* mark_events = nullptr;
-    int64_t* mark_nstored = nullptr;
-    int nmarks = 0, mark_cap = 0;
+    // Blocks of steps in flight.  An event is recorded behind every block a run enqueues (a graph replay of 16 steps, or up to 64
+    // eager steps), in a ring of FLIGHT slots: block k is not enqueued before block k - FLIGHT has completed, so the host never runs
+    // more than FLIGHT blocks (~2 000 AQL packets) ahead of the GPU however long the run is.  gf_sampler_run_to_host hangs its
+    // read-back on the same events (`sink`): a completed block's stored steps are copied to the host before its slot is reused.
+    static constexpr int FLIGHT = 8;
+    hipEvent_t flight_ev[FLIGHT] = {};
+    int64_t flight_nstored[FLIGHT] = {};     // stored steps of every chain that are final once the slot's event has passed
+    int64_t flight_enq = 0, flight_done = 0; // blocks of the current run: enqueued / consumed (waited for and, with a sink, copied)
+    struct HostSink* sink = nullptr;
+};
+// gf_sampler_run_to_host's destination
+struct HostSink {
+    double* chain; double* lnp; int64_t total;     // host arrays of `total` stored steps per chain
+    void* copy_stream; int device;
+    int64_t copied = 0;                            // stored steps already on the host
+    int rc = GF_OK;
+    std::chrono::steady_clock::time_point last_event;   // when the newest consumed block was seen complete
 };
 
 // accessors implemented in gf_capi.hip (gf_model is private to it)
@@ -701,9 +712,7 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_pend_ctl) (void)hipFree(s->d_pend_ctl);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
-    for (int i = 0; i < s->mark_cap; ++i) if (s->mark_events[i]) (void)hipEventDestroy(s->mark_events[i]);
-    delete[] s->mark_events;
-    delete[] s->mark_nstored;
+    for (int i = 0; i < gf_sampler::FLIGHT; ++i) if (s->flight_ev[i]) (void)hipEventDestroy(s->flight_ev[i]);
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_lnp_chain) (void)hipFree(s->d_lnp_chain);
     if (s->d_commons) (void)hipFree(s->d_commons);
@@ -832,22 +841,65 @@ int gf_sampler_reset(gf_sampler* s)
 }
 
 namespace {
-// an event behind what has been enqueued so far; `nstored` stored steps of every chain are final once it has passed
-void mark_block(gf_sampler* s, hipStream_t st, int64_t nstored)
+// the stored steps [sink->copied, upto) of every chain -> host, through the pinned ring, on the sink's stream (synchronous)
+int sink_copy(gf_sampler* s, int64_t upto)
 {
-    if (s->nmarks == s->mark_cap) {
-        const int cap = s->mark_cap ? 2 * s->mark_cap : 64;
-        hipEvent_t* ev = new (std::nothrow) hipEvent_t[cap]();
-        int64_t* ns = new (std::nothrow) int64_t[cap]();
-        if (!ev || !ns) { delete[] ev; delete[] ns; return; }          // no mark: the block is copied with the next one
-        for (int i = 0; i < s->mark_cap; ++i) { ev[i] = s->mark_events[i]; ns[i] = s->mark_nstored[i]; }
-        delete[] s->mark_events; delete[] s->mark_nstored;
-        s->mark_events = ev; s->mark_nstored = ns; s->mark_cap = cap;
+    HostSink* k = s->sink;
+    if (!k || k->rc != GF_OK || upto <= k->copied) return k ? k->rc : GF_OK;
+    if (upto > k->total) upto = k->total;
+    const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
+    const size_t prev = (size_t)k->copied, now = (size_t)(upto - k->copied);
+    int rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->chain) + row * prev, row * (size_t)k->total,
+                                reinterpret_cast<const char*>(s->d_chain) + row * prev, row * (size_t)s->nstore_cap, row * now,
+                                (size_t)s->nchains);
+    if (rc == GF_OK && k->lnp)
+        rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->lnp) + lrow * prev, lrow * (size_t)k->total,
+                                reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * prev, lrow * (size_t)s->nstore_cap, lrow * now,
+                                (size_t)s->nchains);
+    k->rc = rc;
+    k->copied = upto;
+    return rc;
+}
+
+// Block j of the current run: has it completed?  wait = true blocks until it has.  A completed block is consumed -- its stored
+// steps go to the sink, if there is one -- and its slot is free again.  Blocks are consumed in order.
+hipError_t flight_consume(gf_sampler* s, bool wait)
+{
+    const int slot = (int)(s->flight_done % gf_sampler::FLIGHT);
+    hipError_t e = wait ? hipEventSynchronize(s->flight_ev[slot]) : hipEventQuery(s->flight_ev[slot]);
+    if (e != hipSuccess) return e;                                  // hipErrorNotReady: still running
+    if (s->sink) { s->sink->last_event = std::chrono::steady_clock::now(); (void)sink_copy(s, s->flight_nstored[slot]); }
+    ++s->flight_done;
+    return hipSuccess;
+}
+
+// before block `flight_enq` is enqueued: at most FLIGHT - 1 earlier blocks may still be running; and whatever has completed
+// meanwhile is consumed on the way (with a sink: copied while the GPU works on the blocks behind it)
+hipError_t flight_admit(gf_sampler* s)
+{
+    while (s->flight_enq - s->flight_done >= gf_sampler::FLIGHT) {
+        const hipError_t e = flight_consume(s, true);
+        if (e != hipSuccess) return e;
     }
-    hipEvent_t& e = s->mark_events[s->nmarks];
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); return; }
-    if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); return; }
-    s->mark_nstored[s->nmarks++] = nstored;
+    while (s->sink && s->flight_done < s->flight_enq) {
+        const hipError_t e = flight_consume(s, false);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// an event behind the block just enqueued; `nstored` stored steps of every chain are final once it has passed
+hipError_t flight_mark(gf_sampler* s, hipStream_t st, int64_t nstored)
+{
+    const int slot = (int)(s->flight_enq % gf_sampler::FLIGHT);
+    hipEvent_t& e = s->flight_ev[slot];
+    if (!e) { const hipError_t ec = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (ec != hipSuccess) { e = nullptr; return ec; } }
+    const hipError_t er = hipEventRecord(e, st);
+    if (er != hipSuccess) return er;
+    s->flight_nstored[slot] = nstored;
+    ++s->flight_enq;
+    return hipSuccess;
 }
 }  // namespace
 
@@ -897,6 +949,7 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     hs.iteration_base = s->iteration; hs.run_step_base = 0; hs.store_base = s->nstored;
     hs.store = store ? 1 : 0; hs.thin = thin;
     GFS_HIP(hipStreamSynchronize(st));          // earlier runs must be done with the counters
+    s->flight_enq = s->flight_done = 0;         // (so nothing of an earlier run is in flight either)
     GFS_HIP(hipMemcpyAsync(s->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     StretchArgs a;
     a.state = s->d_state;
@@ -999,18 +1052,24 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             }
         }
         while (s->graph && nsteps - done >= GRAPH_STEPS) {
-            hipError_t e = hipGraphLaunch(s->graph, st);
+            hipError_t e = flight_admit(s);
+            if (e != hipSuccess) return sfail(e, "block in flight");
+            e = hipGraphLaunch(s->graph, st);
             if (e != hipSuccess) return sfail(e, "hipGraphLaunch");
             done += GRAPH_STEPS;
-            if (s->marking && store) mark_block(s, st, hs.store_base + (done + thin - 1) / thin);
+            e = flight_mark(s, st, store ? hs.store_base + (done + thin - 1) / thin : hs.store_base);
+            if (e != hipSuccess) return sfail(e, "hipEventRecord");
         }
     }
     while (done < nsteps) {
         const int count = (int)((nsteps - done < 64) ? (nsteps - done) : 64);
-        hipError_t e = steps(count);
+        hipError_t e = flight_admit(s);
+        if (e != hipSuccess) return sfail(e, "block in flight");
+        e = steps(count);
         if (e != hipSuccess) return sfail(e, "stretch launch");
         done += count;
-        if (s->marking && store) mark_block(s, st, hs.store_base + (done + thin - 1) / thin);
+        e = flight_mark(s, st, store ? hs.store_base + (done + thin - 1) / thin : hs.store_base);
+        if (e != hipSuccess) return sfail(e, "hipEventRecord");
     }
     s->iteration += (uint64_t)nsteps;
     s->steps_since_reset += nsteps;
@@ -1037,40 +1096,34 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
     if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
     GFS_HIP(hipSetDevice(device));
-    s->marking = gf_internal_env("GF_RUN_TO_HOST_NO_MARKS", 0) == nullptr;      // diagnostics: no marks = one copy after the run
-    s->nmarks = 0;
-    int rc = gf_sampler_run(s, nsteps, thin, 1);
-    s->marking = false;
-    if (rc != GF_OK) return rc;
-    const int64_t total = s->nstored;                                   // after the run
     void* copy_stream = nullptr;
-    rc = gf_internal_borrow_stream(device, &copy_stream);
-    if (rc != GF_OK) { (void)hipStreamSynchronize((hipStream_t)stream); return rc; }
-    const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
-    int64_t prev = 0;
+    int rc = gf_internal_borrow_stream(device, &copy_stream);
+    if (rc != GF_OK) return rc;
+    // One thread, one pipeline: gf_sampler_run enqueues block after block and, between two blocks, hands every block the GPU has
+    // finished meanwhile to the sink (flight_admit) -- at most FLIGHT blocks are ever enqueued ahead of the GPU, and the copies run
+    // while the GPU works through them.  (Round 3 enqueued the whole run first and only then started to copy.)
+    HostSink sink;
+    sink.chain = chain; sink.lnp = lnprob_chain; sink.total = s->nstored + (nsteps + thin - 1) / thin;
+    sink.copy_stream = copy_stream; sink.device = device;
+    sink.last_event = std::chrono::steady_clock::now();
+    const bool marks = gf_internal_env("GF_RUN_TO_HOST_NO_MARKS", 0) == nullptr;      // diagnostics: no sink during the run = one copy after it
+    s->sink = marks ? &sink : nullptr;
+    rc = gf_sampler_run(s, nsteps, thin, 1);
     hipError_t e = hipSuccess;
-    auto t_done = std::chrono::steady_clock::now();                     // when the run itself was complete on the GPU
-    for (int m = 0; m <= s->nmarks && rc == GF_OK && e == hipSuccess; ++m) {
-        int64_t upto;
-        if (m < s->nmarks) { e = hipEventSynchronize(s->mark_events[m]); upto = s->mark_nstored[m]; }
-        else { e = hipStreamSynchronize((hipStream_t)stream); upto = total; t_done = std::chrono::steady_clock::now(); }   // whatever no mark covered
-        if (e != hipSuccess || upto <= prev) continue;
-        if (upto > total) upto = total;
-        const size_t steps_now = (size_t)(upto - prev);
-        rc = gf_internal_d2h_2d(device, copy_stream, reinterpret_cast<char*>(chain) + row * (size_t)prev, row * (size_t)total,
-                                reinterpret_cast<const char*>(s->d_chain) + row * (size_t)prev, row * (size_t)s->nstore_cap,
-                                row * steps_now, (size_t)s->nchains);
-        if (rc == GF_OK && lnprob_chain)
-            rc = gf_internal_d2h_2d(device, copy_stream, reinterpret_cast<char*>(lnprob_chain) + lrow * (size_t)prev, lrow * (size_t)total,
-                                    reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * (size_t)prev, lrow * (size_t)s->nstore_cap,
-                                    lrow * steps_now, (size_t)s->nchains);
-        prev = upto;
-    }
+    while (rc == GF_OK && e == hipSuccess && s->flight_done < s->flight_enq) e = flight_consume(s, true);   // the blocks still in flight
+    s->sink = nullptr;
     const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+    auto t_done = marks && s->flight_enq > 0 ? sink.last_event : std::chrono::steady_clock::now();        // when the run itself was complete on the GPU
+    if (rc == GF_OK && e == hipSuccess && e2 == hipSuccess && sink.rc == GF_OK) {
+        s->sink = &sink;                                            // whatever no block's event covered (one-launch runs; no marks)
+        (void)sink_copy(s, s->nstored);
+        s->sink = nullptr;
+    }
     (void)hipStreamSynchronize((hipStream_t)copy_stream);
     gf_internal_return_stream(device, copy_stream);
     if (readback_tail_s) *readback_tail_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_done).count();
     if (rc != GF_OK) return rc;
+    if (sink.rc != GF_OK) return sink.rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return sfail(e, "gf_sampler_run_to_host");
     return GF_OK;

@@ -66,6 +66,87 @@ class LocalBackend:
         pass
 
 
+class HostSegment:
+    """One block of host memory mapped by every rank of a node: the destination of a multi-rank scan.
+
+    The reference's N jobs each write their own chain file to one place (golemflavor/mcmc.py:108-126,
+    submitter/mc_texture_dag.py:57-71): N writers, no funnel.  Here every rank reads its own chains back from its own GPU over
+    its own PCIe link straight into its part of this segment, and rank 0 -- which maps the same pages -- has the whole grid
+    without a byte crossing xGMI, a socket or a second PCIe link.
+
+    Backing: a file under /dev/shm when that mount has room, else an anonymous memfd the other ranks open through
+    /proc/<pid>/fd (no size limit but memory).  The name is gone from the filesystem as soon as every rank has mapped it, so
+    nothing outlives the processes.  A COLLECTIVE constructor: every rank of `control` calls it with the same size; on any
+    rank's failure all of them get `.error` set and `.buffer` None, in step."""
+
+    def __init__(self, control, nbytes, root=0, directory=None):
+        import mmap
+        import secrets
+        self.nbytes, self.buffer, self.error, self.kind = int(nbytes), None, None, None
+        self._mm = None
+        rank, err, fd, path = control.rank, "", -1, ""
+        if rank == root:
+            try:
+                d = directory or os.environ.get("GF_SEGMENT_DIR") or "/dev/shm"
+                st = os.statvfs(d) if os.path.isdir(d) else None
+                if st is not None and st.f_bavail * st.f_frsize > self.nbytes + (64 << 20) and os.access(d, os.W_OK):
+                    path = os.path.join(d, "gf_segment_%d_%s" % (os.getpid(), secrets.token_hex(6)))
+                    fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                    self.kind = "file under %s" % d
+                else:
+                    fd = os.memfd_create("gf_segment")
+                    path = "/proc/%d/fd/%d" % (os.getpid(), fd)
+                    self.kind = "memfd"
+                os.ftruncate(fd, max(self.nbytes, 1))
+            except Exception as exc:       # noqa: BLE001
+                err = "%s: %s" % (type(exc).__name__, exc)
+        meta = control.broadcast_bytes(("%s\n%s\n%s" % (err, path, self.kind or "")).encode() if rank == root else b"", root).decode()
+        err, path, kind = meta.split("\n", 2)
+        self.kind = kind or None
+        if not err and rank != root:
+            try:
+                fd = os.open(path, os.O_RDWR)
+            except Exception as exc:       # noqa: BLE001
+                err = "rank %d: %s: %s" % (rank, type(exc).__name__, exc)
+        if not err and fd >= 0:
+            try:
+                self._mm = mmap.mmap(fd, max(self.nbytes, 1), mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+            except Exception as exc:       # noqa: BLE001
+                err = err or "rank %d: mmap: %s: %s" % (rank, type(exc).__name__, exc)
+        errs = control.allgather_bytes(err.encode())       # everybody has mapped it (or said why not): the name can go
+        if rank == root and path and not path.startswith("/proc/"):
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        if fd >= 0:
+            os.close(fd)
+        err = next((e.decode() for e in errs if e), "")
+        if err:
+            self.error = err
+            self.close()
+        else:
+            self.buffer = self._mm
+
+    def array(self, shape, dtype=np.float64, offset=0):
+        """A writable view of the segment (no copy); it keeps the mapping alive."""
+        n = int(np.prod(shape, dtype=np.int64))
+        return np.frombuffer(self._mm, dtype=dtype, count=n, offset=int(offset)).reshape(shape)
+
+    def close(self):
+        """Unmap (a rank that holds views keeps the pages until they are gone: the mapping is closed by the last reference)."""
+        mm, self._mm, self.buffer = self._mm, None, None
+        if mm is not None:
+            try:
+                mm.close()
+            except BufferError:
+                pass                       # views exist: numpy holds the mapping, the pages go with the last of them
+
+
+class ControlPlaneTimeout(TimeoutError):
+    """A rank of the job stopped answering on the control plane (it is alive enough to keep its socket open)."""
+
+
 class SocketBackend:
     """Control plane over TCP, standard library only.  Star topology: rank 0 listens on (addr, port) and relays.
 
@@ -76,10 +157,17 @@ class SocketBackend:
 
     MAGIC = b"GFRDZV1\0"
     PORT_SPAN = 32
-    OP_TIMEOUT = 1800.0       # a collective whose peer has died fails instead of hanging for ever
+    # A collective whose peer has stopped answering fails instead of hanging: seconds a single send / receive may take.  The
+    # default stays well under the 600 s the driver grants a bench run, so that a silent peer turns into a reported error
+    # (socket.timeout on the waiting rank, ConnectionError on the others when it leaves) and not into a killed job;
+    # GF_CONTROL_TIMEOUT or the `op_timeout` argument override it.
+    OP_TIMEOUT = 240.0
 
-    def __init__(self, rank, world, addr=None, port=None, token=None, timeout=120.0):
+    def __init__(self, rank, world, addr=None, port=None, token=None, timeout=120.0, op_timeout=None):
         self.rank, self.world = int(rank), int(world)
+        if op_timeout is None:
+            op_timeout = float(os.environ.get("GF_CONTROL_TIMEOUT", 0) or self.OP_TIMEOUT)
+        self.OP_TIMEOUT = float(op_timeout)
         if not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
@@ -106,7 +194,11 @@ class SocketBackend:
     def _recv_exact(sock, n):
         buf = bytearray()
         while len(buf) < n:
-            chunk = sock.recv(min(n - len(buf), 1 << 20))
+            try:
+                chunk = sock.recv(min(n - len(buf), 1 << 20))
+            except socket.timeout:
+                raise ControlPlaneTimeout("control plane: a peer did not answer within %.0f s (GF_CONTROL_TIMEOUT)"
+                                          % (sock.gettimeout() or 0.0)) from None
             if not chunk:
                 raise ConnectionError("peer closed the rendezvous connection")
             buf += chunk
@@ -338,6 +430,16 @@ class RcclBackend:
     def barrier(self):
         _lib.check(self._L.gf_comm_barrier(self._h), "gf_comm_barrier")
 
+    def info(self):
+        """(nranks, rank, device) as the COMMUNICATOR reports them (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): what
+        RCCL itself saw, not what this object was told."""
+        n, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.check(self._L.gf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)), "gf_comm_info")
+        return n.value, r.value, d.value
+
+    def nranks(self):
+        return self.info()[0]
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             self._L.gf_comm_destroy(self._h)
@@ -349,7 +451,11 @@ class IpcBackend:
     (gf_ipc_export / gf_ipc_gather; 64 bytes each over `control`), the root copies them device to device.  Same
     `gather_device` face as RcclBackend, so `scan.DeviceGather` takes either.  The fallback when the RCCL communicator
     cannot be set up (`open_device_gather`), and the only inter-process DEVICE path a one-GPU box can exercise (RCCL refuses
-    two ranks on one device): tests/test_gpu_mcmc.py runs a two-rank scan over it."""
+    two ranks on one device): tests/test_gpu_mcmc.py runs a two-rank scan over it.
+
+    Every rank takes both collectives of a gather whatever happened locally: a rank whose export failed ships an EMPTY
+    handle, the root treats that as an error and its report reaches everybody (`GolemHipError(GF_ERR_COMM)` on all ranks
+    alike, so that the caller can fall back to the host gather in step)."""
 
     kind = "hipIpc"
 
@@ -358,13 +464,23 @@ class IpcBackend:
         self.rank, self.world, self.device, self.control = int(rank), int(world), int(device), control
         self.init_seconds = 0.0
 
-    def gather_device(self, d_send, d_recv_on_root, bytes_per_rank, root=0):
+    def _export(self, d_send):
         h = (C.c_uint8 * _lib.GF_IPC_HANDLE_BYTES)()
-        _lib.check(self._L.gf_ipc_export(d_send, h), "gf_ipc_export")
-        blobs = self.control.gather_bytes(bytes(h), root)
+        try:
+            _lib.check(self._L.gf_ipc_export(d_send, h), "gf_ipc_export")
+        except Exception as exc:           # noqa: BLE001  -- the peers are on their way into the gather: stay in step
+            return b"", "%s: %s" % (type(exc).__name__, exc)
+        return bytes(h), ""
+
+    def gather_device(self, d_send, d_recv_on_root, bytes_per_rank, root=0):
+        handle, local_err = self._export(d_send)
+        blobs = self.control.gather_bytes(handle, root)
         err = b""
         if self.rank == root:
             try:
+                bad = [r for r, x in enumerate(blobs) if len(x) != _lib.GF_IPC_HANDLE_BYTES]
+                if bad:
+                    raise RuntimeError("no hipIpc handle from rank(s) %s%s" % (bad, (": " + local_err) if local_err else ""))
                 allh = (C.c_uint8 * (_lib.GF_IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(blobs))
                 _lib.check(self._L.gf_ipc_gather(self.device, allh, self.world, self.rank, d_send, d_recv_on_root, int(bytes_per_rank)),
                            "gf_ipc_gather")
@@ -373,35 +489,88 @@ class IpcBackend:
         # the senders keep their blocks until the root is done; the root's outcome reaches everybody
         err = self.control.broadcast_bytes(err, root)
         if err:
-            raise _lib.GolemHipError(_lib.GF_ERR_COMM, "ipc gather failed on rank %d: %s" % (root, err.decode()))
+            raise _lib.GolemHipError(_lib.GF_ERR_COMM, "ipc gather failed on rank %d: %s%s"
+                                     % (root, err.decode(), (" (this rank: %s)" % local_err) if local_err else ""))
+
+    def probe(self):
+        """A 16-byte export / open / copy round trip through `gather_device`, agreed on by all ranks: None, or the error.
+        `open_device_gather` runs it before handing the backend out, so that ranks whose hostnames merely coincide (pods on
+        different machines) or whose GPUs cannot reach each other find out at set-up time, not after the chains are sampled."""
+        err = ""
+        d_send = d_recv = None
+        try:
+            d_send, d_recv = C.c_void_p(), C.c_void_p()
+            _lib.check(self._L.gf_device_malloc(self.device, 256, C.byref(d_send)), "gf_device_malloc")
+            if self.rank == 0:
+                _lib.check(self._L.gf_device_malloc(self.device, 256 * self.world, C.byref(d_recv)), "gf_device_malloc")
+        except Exception as exc:           # noqa: BLE001
+            err = "%s: %s" % (type(exc).__name__, exc)
+            d_send = d_send if d_send is not None and d_send.value else None
+        try:
+            self.gather_device(d_send if d_send is not None else C.c_void_p(), d_recv if self.rank == 0 else None, 16, 0)
+        except Exception as exc:           # noqa: BLE001
+            err = err or "%s: %s" % (type(exc).__name__, exc)
+        for d in (d_send, d_recv):
+            if d is not None and d.value:
+                self._L.gf_device_release(self.device, d)
+        errs = self.control.allgather_bytes(err.encode())
+        return next((e.decode() for e in errs if e), None)
 
     def barrier(self):
         self.control.barrier()
+
+    def nranks(self):
+        return self.world
 
     def close(self):
         pass
 
 
+def node_identity():
+    """What two processes must share to share a node: the kernel's boot id (one per running kernel -- containers and pods of one
+    machine see the same, two machines never do) next to the hostname (which alone says little: pods on different machines
+    are often named alike, and differ on one machine)."""
+    import socket as _socket
+    boot = ""
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            boot = f.read().strip()
+    except OSError:
+        pass
+    return (boot or "no-boot-id:" + _socket.gethostname()).encode()
+
+
 def same_node(control):
-    """True when every rank of `control` runs on this host (hipIpc handles mean nothing elsewhere)."""
-    import socket
-    names = control.allgather_bytes(socket.gethostname().encode())
-    return all(n == names[0] for n in names)
+    """True when every rank of `control` runs on this machine (hipIpc handles and shared host segments mean nothing elsewhere).
+    A collective: every rank calls it."""
+    ids = control.allgather_bytes(node_identity())
+    return all(n == ids[0] for n in ids)
 
 
-def open_device_gather(rank, world, device, control, timeout=120.0):
+def open_device_gather(rank, world, device, control, timeout=120.0, make_id=None, backend_factory=None, ipc_factory=None):
     """The device-to-device gather of a scan: RCCL if its communicator comes up (`open_rccl`), else -- the ranks being on one
     node -- hipIpc.  Returns (backend or None, rccl error or None, stuck): the RCCL error is reported whatever the fallback
-    did; `backend.kind` says which path the chains will take."""
-    b, err, stuck = open_rccl(rank, world, device, control, timeout=timeout)
-    if b is not None or stuck or world < 2:
+    did; `backend.kind` says which path the chains will take.
+
+    What follows an RCCL failure is decided from state EVERY rank holds: `open_rccl` agrees on the error text, but `stuck` (the
+    helper thread still inside ncclCommInitRank) is local -- in the usual failure one rank's init errors out while its peers
+    sit in the bootstrap until the timeout.  So the ranks first exchange their `stuck` flags; if anybody is stuck nobody tries
+    hipIpc (a process with a thread inside RCCL's bootstrap is not one to open peers' memory in), otherwise all of them take
+    `same_node` and the probe together.  The control plane sees the same collectives in the same order on every rank."""
+    b, err, stuck = open_rccl(rank, world, device, control, timeout=timeout, make_id=make_id or make_unique_id,
+                              backend_factory=backend_factory)
+    if b is not None or world < 2:
         return b, err, stuck
-    try:
-        if same_node(control):
-            return IpcBackend(rank, world, device, control), err, False
-    except Exception:                      # noqa: BLE001
-        pass
-    return None, err, False
+    flags = control.allgather_bytes(b"1" if stuck else b"0")
+    if any(f == b"1" for f in flags):
+        return None, err, stuck
+    if not same_node(control):
+        return None, err, False
+    ipc = (ipc_factory or IpcBackend)(rank, world, device, control)
+    perr = ipc.probe()
+    if perr is not None:
+        return None, "%s; hipIpc probe: %s" % (err, perr), False
+    return ipc, err, False
 
 
 def rccl_library_info():

@@ -374,6 +374,15 @@ class DeviceEnsembleSampler:
             nacc.ctypes.data_as(self._C.POINTER(self._C.c_uint32)) if naccepted else None, None), "gf_sampler_get_chain")
         return c, lnp, nacc
 
+    def chain_to_host(self, out):
+        """The stored chain in the device's order, (nchains, nstored, nwalkers, ndim), into an array of the caller's (a rank's
+        region of a shared host segment: scan.SharedHostGather)."""
+        ns = int(self._L.gf_sampler_nstored(self._h))
+        if out.shape != (self.nchains, ns, self.k, self.dim) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %r" % ((self.nchains, ns, self.k, self.dim),))
+        self._lib.check(self._L.gf_sampler_get_chain(self._h, out.ctypes.data_as(self._lib._dp), None, None, None), "gf_sampler_get_chain")
+        return out
+
     @property
     def chain(self):
         """(nwalkers, nsteps, ndim) like emcee-2 [(nchains, nwalkers, nsteps, ndim) when nchains > 1]."""

@@ -4,8 +4,11 @@ posterior of scripts/fr.py / sens.py's scale scan), sharded over one process per
 The reference runs one HTCondor job per grid point (submitter/mc_texture_dag.py:57-71,
 submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`), and all grid points
 of a rank are stacked into ONE device-resident sampler -- one ensemble per posterior, one launch per
-half-step for all of them; chains are gathered at the end: RCCL gather to rank 0 (`gf_comm_gather`)
-straight from the sampler's device chain buffer, one download on rank 0.  No collective on the data path.  The control
+half-step for all of them.  No collective on the data path.  The results are DELIVERED the way the reference's
+jobs deliver theirs -- N writers, no funnel (golemflavor/mcmc.py:108-126): on one node every rank reads its own chains back
+over its own PCIe link into one host segment that rank 0 maps too (`SharedHostGather`, dist.HostSegment), or, with
+--datadir, writes its own files.  Where the ranks do not share a node the chain blocks go GPU to GPU onto rank 0
+(`DeviceGather`: `gf_comm_gather` over RCCL / xGMI, or hipIpc) and cross PCIe once there.  The control
 plane (rendezvous, the RCCL id, barriers) is `dist.SocketBackend` -- no PyTorch in the process; any launcher that sets
 RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT works, torch.distributed.run included.
 
@@ -269,8 +272,9 @@ class DeviceGather:
 
     `stats` (after `run`): block bytes per rank, gathered bytes, seconds of the pack / xGMI / device-to-host phases."""
 
-    def __init__(self, rccl, rank, world, model_for_buffers, root=0):
+    def __init__(self, rccl, rank, world, model_for_buffers, root=0, control=None):
         self.rccl, self.rank, self.world, self.m, self.root = rccl, rank, world, model_for_buffers, root
+        self.control = control         # where an (agreed) hipIpc failure falls back to: blocks to the root over the control plane
         self.stats = {}
         self._dest = None
 
@@ -311,20 +315,39 @@ class DeviceGather:
             t0 = time.perf_counter()
             out = d_send.download(shape[1:], dtype=dtype, out=self.destination(shape[1:]))[None] if self.rank == self.root else None
             self.finish_destination()
-            self.stats.update(xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0)
+            self.stats.update(xgmi_s=0.0, d2h_s=time.perf_counter() - t0, gather_bytes=0, d2h_bytes=int(nbytes) if self.rank == self.root else 0)
             return out
         is_root = self.rank == self.root
         d_recv = self.m.alloc(nbytes * self.world) if is_root else None          # world x block on the root only
         t0 = time.perf_counter()
-        self.rccl.gather_device(d_send.ptr, d_recv.ptr if is_root else None, nbytes, self.root)
+        try:
+            self.rccl.gather_device(d_send.ptr, d_recv.ptr if is_root else None, nbytes, self.root)
+        except _lib.GolemHipError as exc:
+            # a hipIpc failure is AGREED: the root's report has reached every rank (dist.IpcBackend.gather_device), so all of
+            # them land here together and the blocks can still go to the root through the host (an RCCL error is local: re-raise)
+            if getattr(self.rccl, "kind", "") != "hipIpc" or self.control is None or exc.code != _lib.GF_ERR_COMM:
+                raise
+            if is_root:
+                d_recv.free()
+            mine = d_send.download(shape[1:], dtype=dtype)
+            t1 = time.perf_counter()
+            pts = {r: mine[i] for i, r in enumerate(range(self.rank, self.world * shape[1], self.world))}
+            parts = gdist.gather_chains_to_root(pts, self.world * shape[1], self.control, self.root)
+            self.stats.update(xgmi_s=0.0, d2h_s=t1 - t0, host_gather_s=time.perf_counter() - t1, gather_bytes=0,
+                              d2h_bytes=int(nbytes), ipc_error=str(exc))
+            if not is_root:
+                return None
+            return np.stack(parts).reshape((shape[1], self.world) + tuple(shape[2:])).swapaxes(0, 1)
         t1 = time.perf_counter()
         out = d_recv.download(shape, dtype=dtype, out=self.destination(shape)) if is_root else None
         self.finish_destination()
         t2 = time.perf_counter()
         if is_root:
             d_recv.free()
-        # bytes that crossed xGMI into the root: every block but its own
-        self.stats.update(xgmi_s=t1 - t0, d2h_s=t2 - t1, gather_bytes=int(nbytes) * (self.world - 1))
+        # bytes that crossed xGMI into the root -- every block but its own -- counted ONCE, on the root: bench.reduce_phases SUMS
+        # the `*_bytes` keys over the ranks (round 3 counted them on every rank and the line's xGMI rate read `world` times too high)
+        self.stats.update(xgmi_s=t1 - t0, d2h_s=t2 - t1, gather_bytes=int(nbytes) * (self.world - 1) if is_root else 0,
+                          d2h_bytes=int(nbytes) * self.world if is_root else 0)
         return out
 
     def streams_chain(self, first_job):
@@ -371,6 +394,114 @@ class DeviceGather:
         if self.rank != self.root:
             return None
         return [rows[g % self.world, g // self.world] for g in range(n_points)]
+
+
+class SharedHostGather:
+    """Delivery of a multi-rank scan over N PCIe links: every rank reads its OWN chains back from its GPU into its part of one
+    host segment all ranks of the node map (`dist.HostSegment`); rank 0 has the whole grid without a byte crossing xGMI, a
+    socket or somebody else's link.  This is the reference's arrangement -- N jobs, each writing its own chain to one place
+    (golemflavor/mcmc.py:108-126, submitter/mc_texture_dag.py:57-71, submitter/sens_dag.py:75-95) -- and the only one in
+    which eight GPUs shorten a scan whose cost is its read-back (c4_scan_ref / c5_scan_ref at the reference's chain length
+    are 9.4 / 12.6 GB; gathered onto GPU 0 they would all leave through GPU 0's link).
+
+    Every rank runs exactly the ONE-rank code path into its region: C5's chain crosses PCIe while it is sampled
+    (`gf_sampler_run_to_host`), C4's rows are post-processed and read back group by group (`gf_sampler_postprocess_rows`) -- so
+    pack, exchange and download are not three phases but one pipeline per rank, and there is no exchange.
+
+    Layout of the segment: [world][slots][samples per point][width] -- rank r's points in its own contiguous block, grid point g
+    at [g mod world, g div world] (the layout `DeviceGather` produces on rank 0).  If the segment cannot be set up (agreed on by
+    all ranks inside `HostSegment`), every rank reads back into private memory and the blocks go to rank 0 over the control
+    plane (`dist.gather_chains_to_root`); `stats["delivery"]` says which."""
+
+    kind = "shared host segment"
+
+    def __init__(self, control, rank, world, root=0):
+        self.control, self.rank, self.world, self.root = control, int(rank), int(world), int(root)
+        self.rccl = None
+        self.stats = {}
+        self.seg, self.region, self._all = None, None, None
+        self.readback_tail_s = 0.0
+
+    def streams_chain(self, first_job):
+        return first_job.post_model is None and not os.environ.get("GF_SCAN_NO_STREAMED_CHAIN")
+
+    def prepare(self, first_job, n_local, n_points, nsteps):
+        """Collective (every rank calls it, once the burn-in is enqueued: the size is known and the host has nothing else to do):
+        creates / maps the segment.  Pages are mapped by the copy threads as they fill them."""
+        per = nsteps * first_job.nwalkers
+        width = first_job.ndim if first_job.post_model is None else 3 + first_job.ndim
+        slots = gdist.slots_per_rank(n_points, self.world)
+        self._geom = (slots, per, width, n_local, n_points)
+        t0 = time.perf_counter()
+        self.seg = gdist.HostSegment(self.control, self.world * slots * per * width * 8, root=self.root)
+        if self.seg.error is None:
+            self._all = self.seg.array((self.world, slots, per, width))
+            self.region = self._all[self.rank]
+        else:
+            self.region = np.empty((slots, per, width))
+        self.segment_s = time.perf_counter() - t0
+
+    def destination(self, shape):
+        """This rank's region, shaped as the callee wants it: (n_local, nsteps, nwalkers, ndim) for the streamed chain,
+        (n_local, per, width) for post-processed rows."""
+        slots, per, width, n_local, _ = self._geom
+        assert int(np.prod(shape)) == n_local * per * width, (shape, self._geom)
+        return self.region[:n_local].reshape(shape)
+
+    def finish_destination(self):
+        pass
+
+    def run(self, sampler, jobs, order, n_points, streamed=None):
+        slots, per, width, n_local, _ = self._geom
+        first = jobs[order[0]]
+        t0 = time.perf_counter()
+        note = None
+        if streamed is not None:
+            d2h_s = float(self.readback_tail_s)
+            note = "the chain was read back while it was sampled: d2h_s is what was left after the run's last step"
+        elif first.post_model is not None:
+            sampler.postprocess_rows(models=[jobs[g].post_model for g in order], out=self.destination((n_local, per, width)))
+            d2h_s = time.perf_counter() - t0
+            note = "post-processing and read-back overlap, group of chains by group of chains"
+        else:
+            sampler.chain_to_host(self.destination((n_local, sampler.nstored, first.nwalkers, first.ndim)))
+            d2h_s = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        self.stats = GATHER_STATS
+        self.stats.clear()
+        nbytes = n_local * per * width * 8
+        self.stats.update({"ranks": self.world, "slots_per_rank": slots, "pack_s": 0.0, "xgmi_s": 0.0, "gather_bytes": 0,
+                           "d2h_s": d2h_s, "d2h_bytes": int(nbytes), "block_bytes": int(nbytes), "segment_s": self.segment_s,
+                           "delivery": ("shared host segment (%s): every rank reads its own chains back over its own PCIe link"
+                                        % self.seg.kind) if self._all is not None else
+                                       "private read-back, blocks to rank 0 over the control plane (no shared segment: %s)" % self.seg.error})
+        if note:
+            self.stats["note"] = note
+        if self._all is None:
+            # no segment: the host-side stand-in for the gather
+            local = {g: self.region[i] for i, g in enumerate(order)}
+            out = gdist.gather_chains_to_root(local, n_points, self.control, self.root)
+            self.stats["host_gather_s"] = time.perf_counter() - t1
+            return out
+        self.control.barrier()                     # every rank's part is in place
+        self.stats["wait_for_peers_s"] = time.perf_counter() - t1
+        if self.rank != self.root:
+            return None
+        return [self._all[g % self.world, g // self.world] for g in range(n_points)]
+
+    def release(self):
+        """Drop this object's views of the segment and unmap it (the arrays `run` handed out on rank 0 keep the pages for as long
+        as they live)."""
+        self._all = self.region = None
+        if self.seg is not None:
+            self.seg.close()
+            self.seg = None
+
+
+def finite_fraction(arrays, stride_target=4096):
+    """Fraction of finite entries, on a strided sample of each array (the check of a 10 GB result must not cost a pass over it)."""
+    vals = [np.isfinite(c[:: max(1, len(c) // stride_target)]).mean() for c in arrays if len(c)]
+    return float(np.mean(vals)) if vals else float("nan")
 
 
 def point_filename(config, point, a):
@@ -420,44 +551,78 @@ def main(argv=None):
         make = lambda p, g: _SensPoint(p, g, nwalkers=nw, device=device)  # noqa: E731
         evals_per_point = nw * (a.burnin + a.nsteps)
     mine = gdist.shard(len(pts), rank, world)
-    # chain blocks travel over RCCL / xGMI, device buffer to device buffer; if the communicator cannot be set up they are shared
-    # between the node's processes through hipIpc (still device to device), and failing that go through the host control
-    # plane; the RCCL failure is reported either way
-    rccl, rccl_err, stuck = None, None, False
-    if world > 1 or os.environ.get("GF_SCAN_RCCL"):
-        rccl, rccl_err, stuck = gdist.open_device_gather(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
     stacked = not a.no_stack
-    device_gather = stacked and not a.datadir and (rccl is not None or world == 1) and len(pts) >= world
-    if device_gather:
+    can_deliver = stacked and len(pts) >= world       # every rank has a point: the gather objects' collectives line up
+    # How the chains reach their destination, in order of preference:
+    #   --datadir         every rank writes its own points' files, as the reference's jobs do: no gather at all
+    #   one node          every rank reads its chains back over its own PCIe link into one shared host segment (SharedHostGather)
+    #   several nodes     device gather to rank 0 over RCCL / xGMI (or hipIpc), one download (DeviceGather; GF_SCAN_RCCL forces it)
+    #   no communicator   the blocks go to rank 0 through the host control plane
+    want_gather = (not a.datadir) or bool(a.outfile)
+    force_device = bool(os.environ.get("GF_SCAN_RCCL")) or bool(os.environ.get("GF_SCAN_DEVICE_GATHER"))
+    shared = False
+    if world > 1 and want_gather and can_deliver and not force_device:
+        shared = gdist.same_node(control)
+    rccl, rccl_err, stuck = None, None, False
+    if want_gather and not shared and (world > 1 or os.environ.get("GF_SCAN_RCCL")):
+        rccl, rccl_err, stuck = gdist.open_device_gather(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
+    device_gather = want_gather and can_deliver and not shared and (rccl is not None or world == 1)
+    gather_name, chains, local = "local", None, None
+    if a.datadir and not want_gather:
+        local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=stacked)
+        gather_name = "none: every rank saved its own files (--datadir)"
+    elif shared:
+        g = SharedHostGather(control, rank, world)
+        chains = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=True, gather=g)
+        gather_name = g.stats.get("delivery", g.kind)
+        g.release()
+    elif device_gather:
         stage = Model(compile_model(Cf.unitary_paramset(), "PRIOR_ONLY", source_ratio=(1, 2, 0)), device=device)
-        chains = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=True, gather=DeviceGather(rccl, rank, world, stage))
+        chains = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=True,
+                            gather=DeviceGather(rccl, rank, world, stage, control=control))
         stage.close()
+        gather_name = ("%s device gather to rank 0" % rccl.kind) if rccl is not None else "device -> host"
     else:
         local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=stacked)
-        if a.datadir:
-            # the reference's jobs each save their own chain to the shared filesystem; so does every rank here
-            for g in mine:
-                mcmc_utils.save_chains(local[g], os.path.join(a.datadir, point_filename(a.config, pts[g], a)))
         t1 = time.perf_counter()
-        chains = gdist.gather_chains(local, len(pts), control)
+        chains = gdist.gather_chains_to_root(local, len(pts), control)
         PHASES["gather"] = time.perf_counter() - t1
+        gather_name = "socket control plane, blocks to rank 0" if world > 1 else "local"
+    if a.datadir:
+        # the reference's jobs each save their own chain to the shared filesystem; so does every rank here (where the chains
+        # were also gathered for --outfile, rank 0 holds them all and writes the files)
+        todo = local if local is not None else ({g: chains[g] for g in range(len(pts))} if rank == 0 else {})
+        for g, arr in todo.items():
+            mcmc_utils.save_chains(arr, os.path.join(a.datadir, point_filename(a.config, pts[g], a)))
     if rccl is not None:
         rccl.close()
     dt = time.perf_counter() - t0
+    # what the line says about the result: from the gathered chains on rank 0, or -- nothing gathered -- from every rank's own
+    # points through a reduction of two numbers per rank
+    if chains is None and local is not None and a.datadir and not want_gather:
+        vals = [(finite_fraction([local[g]]), local[g].shape) for g in mine]
+        fsum = np.array([sum(v for v, _ in vals), float(len(vals))])
+        tot = control.allgather(fsum).sum(axis=0) if world > 1 else fsum
+        finite = float(tot[0] / max(tot[1], 1.0))
+        shape0 = list(vals[0][1]) if vals else []
+        shapes = control.allgather_bytes(json.dumps(shape0).encode()) if world > 1 else [json.dumps(shape0).encode()]
+        shape0 = next((json.loads(x.decode()) for x in shapes if json.loads(x.decode())), [])
+        chains_shape = [len(pts)] + shape0
+    elif rank == 0:
+        finite = finite_fraction(chains)
+        chains_shape = [len(chains)] + list(chains[0].shape)
     if rank == 0:
         if a.outfile:
             mcmc_utils.save_chains(np.stack(chains), a.outfile)
         print(json.dumps({"config": a.config, "grid_points": len(pts), "ranks": world, "walkers": nw, "burnin": a.burnin,
-                          "nsteps": a.nsteps, "stacked": stacked,
-                          "gather": (("%s device gather to rank 0" % rccl.kind) if rccl is not None else "device -> host") if device_gather
-                          else ("socket control plane" if world > 1 else "local"),
+                          "nsteps": a.nsteps, "stacked": stacked, "gather": gather_name,
                           "rccl_error": rccl_err, "librccl": gdist.rccl_library_info(),
                           "diagnostic_overrides": _lib.diagnostic_overrides(),
                           "gather_stats": GATHER_STATS, "nonunitary": LAST_NONUNITARY,
-                          "chains_shape": [len(chains)] + list(chains[0].shape), "seconds": dt,
+                          "chains_shape": chains_shape, "seconds": dt,
                           "phases": {k: round(v, 4) for k, v in PHASES.items()},
                           "evals_per_s": len(pts) * evals_per_point / dt,
-                          "finite_fraction": float(np.mean([np.isfinite(c).mean() for c in chains]))}), flush=True)
+                          "finite_fraction": finite}), flush=True)
     control.barrier()
     control.close()
     if rccl_err is not None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 3
+#define GF_ABI_VERSION 4
 #define GF_MAX_DIM 16
 #define GF_MAX_BINS 64
 /* CP phases (dcp; the NP matrix's for texture NONE) must stay within +-GF_PHASE_MAX: range (sampled) or value
@@ -296,6 +296,13 @@ int gf_ipc_export(const void* d_ptr, unsigned char* handle64);
 int gf_ipc_gather(int device, const unsigned char* handles, int nranks, int self_rank, const void* d_own, void* d_recv,
                   size_t bytes_per_rank);
 int gf_comm_barrier(gf_comm* c);
+/* ABI 4.  What the COMMUNICATOR itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- the number a bench line
+ * quotes as `rccl_nranks`: how many ranks RCCL saw, not how many the caller asked for.  Any pointer may be NULL. */
+int gf_comm_info(gf_comm* c, int* nranks, int* rank, int* device);
+/* ABI 4.  Device memory without a model handle (the hipIpc probe of golemflavor_amd.dist allocates its 16 bytes before any
+ * posterior exists): hipMalloc / hipFree on `device`. */
+int gf_device_malloc(int device, size_t bytes, void** dptr);
+int gf_device_release(int device, void* dptr);
 const char* gf_comm_last_error(void);                 /* thread-local text of the last failing gf_comm_* call */
 int gf_comm_library_info(char* buf, size_t buflen);   /* "<ncclGetVersion code> <path of the loaded librccl>" */
 

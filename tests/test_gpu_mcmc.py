@@ -239,7 +239,8 @@ def test_scan_gathers_between_processes_on_one_gpu_over_hipipc(config, world, tm
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", GF_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GF_RCCL_TIMEOUT="30", PYTHONDONTWRITEBYTECODE="1")
+                   MASTER_PORT=str(port), GF_RCCL_TIMEOUT="30", PYTHONDONTWRITEBYTECODE="1",
+                   GF_SCAN_DEVICE_GATHER="1")     # (round 4: ranks of one node deliver through a shared host segment unless told otherwise)
         procs.append(subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "many"), config], stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -247,8 +248,78 @@ def test_scan_gathers_between_processes_on_one_gpu_over_hipipc(config, world, tm
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["ranks"] == world and line["gather"] == "hipIpc device gather to rank 0" and "ncclCommInitRank" in line["rccl_error"]
     assert line["gather_stats"]["gather_bytes"] > 0 and line["gather_stats"]["ranks"] == world
+    # bytes into the root: every block but its own, counted once
+    assert line["gather_stats"]["gather_bytes"] == line["gather_stats"]["block_bytes"] * (world - 1)
     a, b = np.load(str(tmp_path / "one.npy")), np.load(str(tmp_path / "many.npy"))
     assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("config,world", [("C4", 2), ("C5", 2), ("C4", 3), ("C5", 3)])
+def test_scan_delivers_over_every_rank_s_own_link_into_a_shared_host_segment(config, world, tmp_path, capsys):
+    """Round 4: the multi-rank delivery.  `world` ranks in separate processes (on the one GPU this box has), no communicator at
+    all: every rank reads its OWN chains back -- C5's while they are sampled, C4's rows group by group behind the post-processing
+    -- into its part of one host segment (dist.HostSegment), which rank 0 maps too; a barrier is all that crosses the control
+    plane.  Five grid points: ragged over 2 and 3 ranks.  The result must be the single-rank scan's, bit for bit, the exit
+    status 0 (no RCCL was asked for), and the accounting must show `world` links with each rank's own bytes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from golemflavor_amd import scan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scan.main(["--config", config, "--points", "5", "--nwalkers", "32", "--burnin", "6", "--nsteps", "9", "--outfile", str(tmp_path / "one")])
+    capsys.readouterr()
+    script = tmp_path / "child.py"
+    script.write_text(_TWO_RANK_CHILD)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", GF_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "many"), config], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-1500:]) for p, o in zip(procs, outs)]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["ranks"] == world and line["gather"].startswith("shared host segment") and line["rccl_error"] is None
+    st = line["gather_stats"]
+    width = 9 if config == "C4" else 12
+    assert st["gather_bytes"] == 0 and st["d2h_bytes"] == len(gdist.shard(5, 0, world)) * 9 * 32 * width * 8    # rank 0's own points only
+    a, b = np.load(str(tmp_path / "one.npy")), np.load(str(tmp_path / "many.npy"))
+    assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def test_scan_with_datadir_gathers_nothing(tmp_path, capsys):
+    """--datadir on two ranks: every rank writes the files of its own grid points, as the reference's jobs do
+    (golemflavor/mcmc.py:108-126) -- no chain crosses anything; the line's finite_fraction comes from a two-number reduction.
+    The files are the single-rank run's, bit for bit."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from golemflavor_amd import scan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--config", "C4", "--points", "5", "--nwalkers", "32", "--burnin", "6", "--nsteps", "9"]
+    scan.main(args + ["--datadir", str(tmp_path / "one")])
+    one = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    child = tmp_path / "child.py"
+    child.write_text("import sys\nsys.path.insert(0, sys.argv[1])\nfrom golemflavor_amd import scan\nscan.main(sys.argv[2:])\n")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", GF_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(child), root] + args + ["--datadir", str(tmp_path / "two")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-1500:]) for p, o in zip(procs, outs)]
+    line = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
+    assert line["gather"].startswith("none") and line["chains_shape"] == [5, 9 * 32, 9] == one["chains_shape"]
+    assert line["finite_fraction"] == pytest.approx(one["finite_fraction"])
+    f1, f2 = sorted(os.listdir(str(tmp_path / "one"))), sorted(os.listdir(str(tmp_path / "two")))
+    assert f1 == f2 and len(f1) == 5
+    for f in f1:
+        assert np.array_equal(np.load(str(tmp_path / "one" / f)), np.load(str(tmp_path / "two" / f)), equal_nan=True)
 
 
 def test_scan_rows_to_host_equal_rows_on_device():

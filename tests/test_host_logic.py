@@ -424,3 +424,34 @@ def test_host_prepare_keeps_the_content_and_tolerates_a_concurrent_writer():
     before = rss()
     assert L.gf_host_prepare_n(c.ctypes.data_as(C.c_void_p), c.nbytes, 4) == _lib.GF_OK
     assert rss() - before > 200 << 20
+
+
+def test_host_prepare_poke_path_maps_pages_and_keeps_the_content(tmp_path):
+    """The fallback of gf_host_prepare where madvise(MADV_POPULATE_WRITE) is refused (kernels before 5.14): a locked
+    read-modify-write of one byte per page.  Forced with GF_PREPARE_FORCE_POKE in a child process (the switch is read once):
+    the pages must become resident and what the buffer held must stay."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from golemflavor_amd import _lib
+L = _lib.lib()
+def rss():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+c = np.empty((192 << 20) // 8)
+before = rss()
+assert L.gf_host_prepare_n(c.ctypes.data_as(C.c_void_p), c.nbytes, 3) == _lib.GF_OK
+grown = rss() - before
+a = np.arange((32 << 20) // 8, dtype=np.float64)
+assert L.gf_host_prepare(a.ctypes.data_as(C.c_void_p), a.nbytes) == _lib.GF_OK
+print(grown, bool(np.array_equal(a, np.arange(a.size, dtype=np.float64))), "GF_PREPARE_FORCE_POKE" in _lib.diagnostic_overrides())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GF_PREPARE_FORCE_POKE="1", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    grown, same, echoed = out.stdout.split()
+    assert int(grown) > 150 << 20 and same == "True" and echoed == "True"
