@@ -11,12 +11,12 @@ export TMPDIR=/tmp
 ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler --no-extras"
 # the trace pass runs bench.py's default step counts, so that its per-kernel average is the number bench.py prints
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-sampler --no-extras > $OUT/bench_trace.json 2> $OUT/trace.err
-# ... and one trace of the whole default command (sub-records included): every kernel of every BASELINE configuration
-# (GF_SCAN_NO_STREAMED_CHAIN=1: the C5 scans sample first and read back afterwards in this pass.  With the read-back overlapped --
-# the default -- rocprofv3's kernel trace of THIS command segfaults inside hipGraphLaunch, in rocprofiler's own frames, about
-# 35 graph replays into c5_scan_ref's run; the same command passes without the profiler, with GF_SAMPLER_NO_GRAPH=1 under it, and
-# the four scans on their own pass under it in either mode: profiles/r03/README.txt.  Kernel durations are the same either way.)
-GF_SCAN_NO_STREAMED_CHAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 bench.py --no-cpu-baseline > $OUT/bench_trace_full.json 2> $OUT/trace_full.err
+# ... and one trace of the whole DEFAULT command (sub-records included): every kernel of every BASELINE configuration, C5's chain read
+# back while it is sampled, graph replays, no GF_* switch.  ROC_AQL_QUEUE_SIZE=131072 (a variable of the HIP runtime): the command
+# dispatches ~19 000 kernels, HIP's default AQL ring holds 16 384 packets, and under rocprofv3's queue interception a hipGraphLaunch
+# batch that straddles the wrap of the ring is read past its end (SIGSEGV in the profiling stack; stand-alone reproducer
+# tools/graph_wrap_probe.hip, record profiles/r04/rocprof_graph_wrap.txt).  With an 8 MiB ring the run never wraps.
+ROC_AQL_QUEUE_SIZE=131072 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 bench.py --no-cpu-baseline > $OUT/bench_trace_full.json 2> $OUT/trace_full.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
