@@ -2,6 +2,7 @@
 // Owns: descriptor validation, derivation of the per-run constants, device/stream/staging-buffer
 // management and the launch calls.  There is deliberately no CPU evaluation path in this library.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <pthread.h>
 #include <sys/mman.h>
 
@@ -1311,6 +1312,34 @@ int gf_internal_d2h_2d(int device, void* stream, void* dst_host, size_t dpitch, 
     consumer.join();
     if (e != hipSuccess) return hip_fail(e, "gf_internal_d2h_2d");
     if (failed.load()) { std::snprintf(g_err, sizeof(g_err), "gf_internal_d2h_2d: event wait failed"); return GF_ERR_HIP; }
+    return GF_OK;
+}
+
+// diagnostics (tools/readback_ab.py, not part of the ABI): what the link delivers in this process -- `bytes` of device memory copied into
+// PINNED host memory in 64 MiB pieces, no host copy behind them; GB/s
+int gf_internal_pinned_d2h_rate(int device, size_t bytes, double* gbps)
+{
+    if (!gbps || bytes < ((size_t)64 << 20)) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipSetDevice(device));
+    const size_t piece = (size_t)64 << 20;
+    void *h = nullptr, *d = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e = hipHostMalloc(&h, 2 * piece, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d, piece);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, piece, hipMemcpyDeviceToHost, st);          // warm-up
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t done = 0;
+    for (int k = 0; e == hipSuccess && done < bytes; ++k, done += piece)
+        e = hipMemcpyAsync(static_cast<char*>(h) + (k & 1) * piece, d, piece, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st) (void)hipStreamDestroy(st);
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    if (e != hipSuccess) return hip_fail(e, "gf_internal_pinned_d2h_rate");
+    *gbps = (double)done / dt / 1e9;
     return GF_OK;
 }
 

@@ -31,6 +31,7 @@ extern "C" const char* gf_internal_env(const char* name, int affects_results);  
 #include "gf_device.hpp"
 #include "gf_bsm_device.hpp"
 #include "gf_launch.h"
+#include "gf_unitarity_teams.hpp"      // Team9: the reference's unitarity chain on nine lanes (k_stretch_chain settles its own parked proposals)
 
 namespace {
 using namespace gfdev;
@@ -499,6 +500,380 @@ hipError_t launch_persist(int mode, int ndim, int nchains, int threads, size_t l
     }
 }
 
+// ---- one workgroup per CHAIN, BSM posteriors ------------------------------------------------------------------------------------
+// The grid kernels above advance ALL chains of a sampler half-step by half-step, and since round 3 a half-step is followed by
+// k_stretch_settle, which takes the exact (emulated x87) unitarity verdict of the proposals the in-kernel tiers could not settle:
+// ~66 us of ONE walker's dependent arithmetic.  Measured on the C5 scan (256 chains x 512 walkers, profiles/r03/
+// arbitration_latency.txt): ~120 of 65 536 proposals park per half-step, in 30 of the 256 chains -- and all 256 chains, which share
+// nothing, waited 66 us for them at the kernel boundary: 37 us of proposals + 67 us of settling per half-step.
+//
+// Chains are independent (emcee runs them as separate jobs: submitter/sens_dag.py:75-95), so here a workgroup OWNS a chain for a
+// whole block of steps: its half-steps follow each other behind a workgroup barrier, the walkers stay where the grid kernels
+// keep them (HBM; a chain's 49 KB live in this CU's caches), and when a half-step parks proposals the SAME workgroup settles
+// them on the spot -- its four waves become 56 nine-lane teams (gf_unitarity_teams.hpp), a walker's undecided bins fan out over
+// them, the last part to finish completes the walker's accept step -- and goes on.  Nobody else waits.  Same Philox counters,
+// same proposal_lnprob instance, same chain arithmetic, same accept rule as k_stretch + k_stretch_settle: the chain is bitwise
+// the grid sampler's (tests/test_gpu_sampler.py).
+struct ChainArgs {
+    const GfCommon* commons;        // [nmodels]
+    const GfBsm* const* tbs;        // [nmodels] (nmodels > 1), else null
+    const GfBsm* tb;                // nmodels == 1
+    const double* const* ptabs;     // [nmodels]
+    int32_t nmodels;                // 1: every chain samples commons[0]
+    int32_t nwalkers;
+    double* pos;                    // [nchains][nwalkers][ndim]
+    double* lnp;                    // [nchains][nwalkers]
+    uint32_t* naccept;              // [nchains][nwalkers]
+    uint32_t* flags;                // [0]: proposals the reference would have raised on
+    double* pend_rows;              // [nchains * nwalkers / 2][GF_PEND_STRIDE]: a parked proposal's row
+    double* chain;                  // [nchains][nstore_cap][nwalkers][ndim] or null
+    double* lnp_chain;
+    int64_t nstore_cap, store_base; // chain slot of the RUN's first stored step
+    uint64_t seed, iteration_base;  // Philox counter word of this launch's first step
+    int64_t run_step_base;          // steps of the run done before this launch (thinning counts from the run's start)
+    int32_t nsteps, thin, store;
+    double a;
+    const uint64_t* stream_ids;     // as StretchArgs::stream_ids
+    double* lazy_rows;              // [nchains][lazy_cap][GF_PEND_STRIDE]: undecided proposals that are rejected either way ...
+    unsigned long long* lazy_mask;  // [nchains][lazy_cap]: ... with their undecided bins (k_stretch_chain settles them in bulk)
+    int32_t lazy_cap;
+    unsigned long long* stats;      // [nchains][8] (may be null): per chain, ns on the 100 MHz wall clock spent in [0] proposals, [1] settling
+                                    // parked proposals, [2] bulk settlement; [3] proposals waited for, [4] passes that waited, [5] settled in bulk,
+                                    // [6] passes, [7] bulk settlements
+};
+
+// workgroup of the per-chain sampler: eight waves -- two per SIMD, 256 VGPRs each -- = 56 nine-lane teams when proposals are settled
+constexpr int CH_BLOCK = 512;
+constexpr int CH_WAVES = CH_BLOCK / GF_WAVE;
+
+// LDS pointers that stay LDS pointers across a call (ds_ instructions, not flat_)
+typedef __attribute__((address_space(3))) double* LdsD;
+typedef __attribute__((address_space(3))) unsigned int* LdsU;
+typedef __attribute__((address_space(3))) int* LdsI;
+typedef __attribute__((address_space(3))) unsigned long long* LdsL;
+
+// One walker's proposal of k_stretch_chain -- exactly as stretch_body makes it -- as a function of its own: the kernel around it holds
+// the nine-lane teams' code (~210 VGPRs of its own), and compiled as one body for eight waves per CU (256 VGPRs) the allocator spilled
+// inside the evaluation's bin loop (36 us per pass instead of 24).  Out of line, each side has the whole budget.
+template <int NDIM>
+__device__ __attribute__((noinline)) void chain_propose(const ChainArgs& s, const GfCommon& c, const GfBsm* __restrict__ tb, LdsD ctab_l, LdsD ttab_l,
+                                                        LdsD row_l, const int chain, const int k, const int half, const uint64_t iteration,
+                                                        const bool store_now, const int64_t store_index, const uint64_t sid, double* my_pend,
+                                                        double* lz_rows, unsigned long long* lz_mask, LdsU pk_n, LdsI pk_k, LdsL pk_mask, LdsU lz_n)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    const double* ctab = (const double*)ctab_l;
+    const double* ttab = (const double*)ttab_l;
+    double* row = (double*)row_l;
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int nw = s.nwalkers, nhalf = nw / 2;
+    const int cbase = (1 - half) * nhalf;
+    const uint32_t k0s = (uint32_t)s.seed, k1s = (uint32_t)(s.seed >> 32);
+    {
+        // ---- the proposal, exactly as stretch_body makes it
+        const uint64_t g = sid * (uint64_t)nhalf + (uint64_t)k;
+        const int w = half * nhalf + k;
+        uint32_t r[4];
+        philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(2 * iteration + half),
+                     (uint32_t)((2 * iteration + half) >> 32), k0s, k1s, r);
+        const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+        const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
+        const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+        const double zr = fma(s.a - 1.0, u1, 1.0);
+        const double z = zr * zr / s.a;
+        const int64_t wi = (int64_t)chain * nw + w;
+        const double* sk = s.pos + wi * ndim;
+        const double* cj = s.pos + ((int64_t)chain * nw + cbase + j) * ndim;
+    #pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (!NDIM && d >= ndim) break;
+            const double cv = cj[d];
+            row[d] = fma(-z, cv - sk[d], cv);
+        }
+        int st;
+        unsigned long long pending;
+        const double lnq = proposal_lnprob<NDIM, MODE_BSM_GAUSS, 1>(c, tb, ctab, ttab, row, ndim, st, 0, nullptr, pending);
+        const double lnk = s.lnp[wi];
+        double zp = 1.0;
+        for (int d = 1; d < ndim; ++d) zp *= z;
+        const double lhs = log(zp / u3);
+        bool accept = lhs > lnk - lnq;                    // false for NaN and for lnq = -inf
+        if (pending != 0ull && accept) {
+            // undecided unitarity and the verdict DECIDES: park it; this workgroup settles it below, before anybody
+            // reads this walker again
+            double* dst = my_pend + (size_t)k * GF_PEND_STRIDE;
+            for (int d = 0; d < ndim; ++d) dst[d] = row[d];
+            dst[GF_MAX_DIM] = lnq;
+            dst[GF_MAX_DIM + 1] = lhs;
+            const unsigned int at = atomicAdd((unsigned int*)pk_n, 1u);
+            pk_k[at] = k;
+            pk_mask[at] = pending;
+        } else {
+            if (pending != 0ull) {
+                // undecided, but rejected either way: only the count wants the verdict -- later
+                const unsigned int at = atomicAdd((unsigned int*)lz_n, 1u);
+                double* dst = lz_rows + (size_t)at * GF_PEND_STRIDE;
+                for (int d = 0; d < ndim; ++d) dst[d] = row[d];
+                lz_mask[at] = pending;
+            }
+            if (st == ST_NON_UNITARY) { accept = false; atomicAdd(s.flags, 1u); }      // the reference raises inside ln_prob here
+            if (accept) {
+                double* dst = s.pos + wi * ndim;
+    #pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (!NDIM && d >= ndim) break;
+                    dst[d] = row[d];
+                }
+                s.lnp[wi] = lnq;
+                s.naccept[wi] += 1u;
+            }
+            if (store_now) {
+                double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * nw + w) * ndim;
+    #pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (!NDIM && d >= ndim) break;
+                    dst[d] = accept ? row[d] : sk[d];
+                }
+                if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = accept ? lnq : lnk;
+            }
+        }
+    }
+}
+
+// The workgroup's eight waves as 56 nine-lane teams on a list of `count` proposals whose unitarity is undecided.  Two stages per chunk
+// of up to WT_CAP walkers, so that nothing is computed twice and no team idles behind a walker with many bins:
+//   A  a team per WALKER builds the walker's two Hamiltonian terms (fr.py:380-394 in emulated x87: ~16 us) and leaves them in LDS;
+//   B  a team per (walker, bin) PAIR takes the terms from LDS and evaluates that one energy bin (~23 us).  Pairs are handed out
+//      rank-major -- every walker's highest undecided energy first (the likeliest to fail), then the second-highest ... -- and a pair
+//      whose walker has failed meanwhile (fr.py:493-494: the reference raises at the first) is dropped unevaluated.  The last pair of
+//      a walker to report calls done(item, failed).
+// (k_stretch_settle, gf_unitarity.hip, gives every part of a walker its own copy of the terms: right for a kernel the whole GPU runs,
+// 3 584 teams for a few hundred pairs; here 56 teams face up to ~100 pairs per half-step of a chain in the failing region, and the
+// terms were 40 % of the work.)
+//   row_of(item) -> the proposal's row (theta at [0, ndim))       mask_of(item) -> its undecided bins (non-zero)
+//   head, aux -> LDS words;   ctl -> LDS [2 * CH_BLOCK], zero on entry and on exit;   wt -> LDS [WT_CAP][9][8] doubles
+// A workgroup-uniform call: it contains workgroup barriers.
+constexpr int WT_CAP = 64;                             // walkers whose terms are held at once (64 x 576 B = 36 KB)
+constexpr int WT_DOUBLES = WT_CAP * Team9::LANES * 8;
+__device__ __forceinline__ int nth_bit_from_top(unsigned long long m, unsigned int n)
+{
+    for (unsigned int i = 0; i < n; ++i) m &= ~(1ull << (63 - __clzll((long long)m)));
+    return 63 - __clzll((long long)m);
+}
+template <class RowOf, class MaskOf, class Done>
+__device__ __forceinline__ void chain_settle(double* uni, double* wt, unsigned int count, unsigned int* head, unsigned int* aux, unsigned int* ctl,
+                                             const GfCommon& c, const GfBsm* __restrict__ tb, RowOf row_of, MaskOf mask_of, Done done)
+{
+    const int lane = threadIdx.x & (GF_WAVE - 1), wave = threadIdx.x / GF_WAVE;
+    const int grp = lane / Team9::LANES;
+    const bool team_active = grp < Team9::PER_WAVE;                                    // lane 63 has no team
+    const int tl = lane - grp * Team9::LANES;                                          // lane within the team
+    Team9 tm;
+    tm.init(uni + ((size_t)wave * Team9::PER_WAVE + (team_active ? grp : 0)) * Team9::DOUBLES, tl);
+    const bool lead = tm.leader();
+    for (unsigned int first = 0; first < count; first += (unsigned int)WT_CAP) {
+        const unsigned int nw_chunk = count - first < (unsigned int)WT_CAP ? count - first : (unsigned int)WT_CAP;
+        if (threadIdx.x == 0) { *head = 0u; *aux = 0u; }
+        __syncthreads();
+        // ---- A: the walkers' terms
+        for (;;) {
+            const unsigned long long nb = __ballot(team_active && lead);
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)nb) - 1;
+            if (lane == leader) base = atomicAdd(head, (unsigned int)__popcll(nb));
+            base = (unsigned int)__shfl((int)base, leader);
+            const unsigned int idx = base + (unsigned int)grp;                       // teams 0..6 of the wave take consecutive walkers
+            const bool have = team_active && idx < nw_chunk;
+            if (__ballot(have) == 0ull) break;                                        // wave-uniform: the chunk's walkers are handed out
+            if (have) {
+                const unsigned int item = first + idx;
+                tm.terms(c, *tb, row_of(item), 0, 1, 0, GF_PEND_STRIDE);
+                double* w = wt + ((size_t)idx * Team9::LANES + tl) * 8;
+                w[0] = tm.hs.re.hi; w[1] = tm.hs.re.lo; w[2] = tm.hs.im.hi; w[3] = tm.hs.im.lo;
+                w[4] = tm.hn.re.hi; w[5] = tm.hn.re.lo; w[6] = tm.hn.im.hi; w[7] = tm.hn.im.lo;
+                if (lead) atomicMax(aux, (unsigned int)__popcll(mask_of(item)));      // the most bins any walker of the chunk brings
+            }
+        }
+        __syncthreads();
+        const unsigned int maxb = *aux;
+        const unsigned int npairs = nw_chunk * maxb;                                  // rank-major grid of pairs; holes where a walker has fewer bins
+        __syncthreads();
+        if (threadIdx.x == 0) *head = 0u;
+        __syncthreads();
+        // ---- B: one energy bin per team and round
+        for (;;) {
+            const unsigned long long nb = __ballot(team_active && lead);
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)nb) - 1;
+            if (lane == leader) base = atomicAdd(head, (unsigned int)__popcll(nb));
+            base = (unsigned int)__shfl((int)base, leader);
+            const unsigned int v = base + (unsigned int)grp;
+            const bool inrange = team_active && v < npairs;
+            if (__ballot(inrange) == 0ull) break;
+            if (inrange) {
+                const unsigned int idx = v % nw_chunk, rank = v / nw_chunk;
+                const unsigned int item = first + idx;
+                const unsigned long long im = mask_of(item);
+                const unsigned int nbits = (unsigned int)__popcll(im);
+                if (rank < nbits) {
+                    bool failed = false;
+                    if (__atomic_load_n(&ctl[2 * idx + 1], __ATOMIC_RELAXED) == 0u) {   // else: another bin of this walker has failed already
+                        const double* w = wt + ((size_t)idx * Team9::LANES + tl) * 8;
+                        tm.hs.re.hi = w[0]; tm.hs.re.lo = w[1]; tm.hs.im.hi = w[2]; tm.hs.im.lo = w[3];
+                        tm.hn.re.hi = w[4]; tm.hn.re.lo = w[5]; tm.hn.im.hi = w[6]; tm.hn.im.lo = w[7];
+                        const int kk = nth_bit_from_top(im, rank);
+                        const double res = tm.bin(tb->inv2e[kk], tb->epow[kk]);
+                        failed = !(res < 1e-7);                                       // fr.py:493-494 (NaN raises too)
+                    }
+                    if (lead) {
+                        if (failed) atomicOr(&ctl[2 * idx + 1], 1u);
+                        __threadfence_block();
+                        const unsigned int before = atomicAdd(&ctl[2 * idx], 1u);
+                        if (before == nbits - 1u) {                                   // the last pair of the walker to report
+                            __threadfence_block();
+                            const bool bad = atomicOr(&ctl[2 * idx + 1], 0u) != 0u;
+                            ctl[2 * idx] = 0u;
+                            ctl[2 * idx + 1] = 0u;
+                            done(item, bad);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NDIM>
+__global__ __launch_bounds__(CH_BLOCK) void k_stretch_chain(const ChainArgs s)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    constexpr int TEAMS = CH_WAVES * Team9::PER_WAVE;                       // 56 nine-lane teams
+    constexpr int TEAM_DOUBLES = TEAMS * Team9::DOUBLES;
+    constexpr int TILE_DOUBLES = CH_WAVES * GF_WAVE * ND;
+    // one buffer, two lives: the proposals' rows while a pass of the half-step is evaluated, the teams' slots while its parked
+    // proposals are settled (their rows are in `pend_rows` by then)
+    __shared__ __attribute__((aligned(16))) double uni[TEAM_DOUBLES > TILE_DOUBLES ? TEAM_DOUBLES : TILE_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
+    __shared__ unsigned long long pk_mask[CH_BLOCK];      // the pass's parked proposals: undecided bins ...
+    __shared__ int pk_k[CH_BLOCK];                        // ... walker slot in the active half
+    __shared__ unsigned int pk_ctl[2 * CH_BLOCK];         // per listed proposal: parts finished, one of them failed (zero between uses)
+    __shared__ unsigned int pk_n, pk_head, pk_aux, lz_n;
+    __shared__ __attribute__((aligned(16))) double wt[WT_DOUBLES];    // chain_settle: the Hamiltonian terms of the walkers being settled
+
+    const int chain = blockIdx.x;
+    const GfCommon& c = s.commons[s.nmodels > 1 ? chain : 0];
+    const GfBsm* __restrict__ tb = s.nmodels > 1 ? s.tbs[chain] : s.tb;
+    const double* __restrict__ ptab = s.ptabs[s.nmodels > 1 ? chain : 0];
+    double* ttab = ctab + GF_MAX_DIM * 4;
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 18) {                                // as stretch_body: the texture's two projectors
+        const int k = threadIdx.x - 64, e = k >> 1;
+        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
+        const bool im = e == 4 || e == 6 || e == 8;
+        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
+        ttab[k] = srcp[idx];
+    }
+    for (int i = threadIdx.x; i < 2 * CH_BLOCK; i += CH_BLOCK) pk_ctl[i] = 0u;
+    if (threadIdx.x == 0) lz_n = 0u;
+    __syncthreads();
+
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int lane = threadIdx.x & (GF_WAVE - 1), wave = threadIdx.x / GF_WAVE;
+    const int nw = s.nwalkers, nhalf = nw / 2;
+    const uint64_t sid = s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain;
+    const uint32_t k0s = (uint32_t)s.seed, k1s = (uint32_t)(s.seed >> 32);
+    double* row = uni + (size_t)wave * GF_WAVE * ND + (size_t)lane * ndim;          // (stretch_body: tiles[wave] + lane * ndim)
+    double* const my_pend = s.pend_rows + (size_t)chain * nhalf * GF_PEND_STRIDE;    // this chain's parked rows, by walker slot
+    // proposals that are REJECTED WHATEVER THEIR VERDICT (the accept test fails even if they are unitary): the chain does not wait
+    // for them -- the verdict only feeds the count of proposals the reference would have raised on.  Their rows queue up here
+    // and are settled in bulk when the list fills and at the end of the launch.
+    double* const lz_rows = s.lazy_rows + (size_t)chain * s.lazy_cap * GF_PEND_STRIDE;
+    unsigned long long* const lz_mask = s.lazy_mask + (size_t)chain * s.lazy_cap;
+    unsigned long long* const stat = s.stats ? s.stats + (size_t)chain * 8 : nullptr;
+    auto flush_lazy = [&]() {                              // workgroup-uniform call; barriers inside
+        const unsigned int n = lz_n;
+        if (n != 0u) {
+            const unsigned long long t0 = wall_clock64();
+            if (threadIdx.x == 0) pk_head = 0u;
+            __syncthreads();
+            chain_settle(uni, wt, n, &pk_head, &pk_aux, pk_ctl, c, tb,
+                         [&](unsigned int i) { return lz_rows + (size_t)i * GF_PEND_STRIDE; },
+                         [&](unsigned int i) { return lz_mask[i]; },
+                         [&](unsigned int, bool bad) { if (bad) atomicAdd(s.flags, 1u); });
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                lz_n = 0u;
+                if (stat) { stat[2] += 10ull * (wall_clock64() - t0); stat[5] += n; stat[7] += 1ull; }
+            }
+            __syncthreads();
+        }
+    };
+
+    for (int step = 0; step < s.nsteps; ++step) {
+        const uint64_t iteration = s.iteration_base + (uint64_t)step;
+        const int64_t run_step = s.run_step_base + step;
+        const bool store_now = s.store != 0 && s.chain != nullptr && (run_step % s.thin) == 0;
+        const int64_t store_index = s.store_base + (run_step + s.thin - 1) / s.thin;
+        for (int half = 0; half < 2; ++half) {
+            const int cbase = (1 - half) * nhalf;
+            for (int kb = 0; kb < nhalf; kb += CH_BLOCK) {
+                if (lz_n + (unsigned int)(nhalf < CH_BLOCK ? nhalf : CH_BLOCK) > (unsigned int)s.lazy_cap) flush_lazy();   // (uniform: lz_n is stable between barriers)
+                if (threadIdx.x == 0) { pk_n = 0u; pk_head = 0u; }
+                __syncthreads();
+                const unsigned long long t_pass = wall_clock64();
+                const int k = kb + (int)threadIdx.x;
+                if (k < nhalf)
+                    chain_propose<NDIM>(s, c, tb, (LdsD)ctab, (LdsD)ttab, (LdsD)row, chain, k, half, iteration, store_now, store_index, sid,
+                                        my_pend, lz_rows, lz_mask, (LdsU)&pk_n, (LdsI)pk_k, (LdsL)pk_mask, (LdsU)&lz_n);
+                __syncthreads();                                      // rows are done with; pk_n is final; this pass's updates are visible
+                const unsigned int count = pk_n;
+                const unsigned long long t_settle = wall_clock64();
+                if (threadIdx.x == 0 && stat) { stat[0] += 10ull * (t_settle - t_pass); stat[6] += 1ull; }
+                if (count != 0u) {
+                    chain_settle(uni, wt, count, &pk_head, &pk_aux, pk_ctl, c, tb,
+                                 [&](unsigned int i) { return my_pend + (size_t)pk_k[i] * GF_PEND_STRIDE; },
+                                 [&](unsigned int i) { return pk_mask[i]; },
+                                 [&](unsigned int i, bool bad) {
+                                     // the walker's accept step, as k_stretch_settle ends it: the accept test itself has passed
+                                     const double* prow = my_pend + (size_t)pk_k[i] * GF_PEND_STRIDE;
+                                     const int w = half * nhalf + pk_k[i];
+                                     const int64_t wi = (int64_t)chain * nw + w;
+                                     const double lnq = prow[GF_MAX_DIM];
+                                     const double lnk = s.lnp[wi];
+                                     const bool accept = !bad;
+                                     if (bad) atomicAdd(s.flags, 1u);
+                                     double* pw = s.pos + wi * ndim;
+                                     if (store_now) {
+                                         double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * nw + w) * ndim;
+                                         for (int d = 0; d < ndim; ++d) dst[d] = accept ? prow[d] : pw[d];
+                                         if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = accept ? lnq : lnk;
+                                     }
+                                     if (accept) {
+                                         for (int d = 0; d < ndim; ++d) pw[d] = prow[d];
+                                         s.lnp[wi] = lnq;
+                                         s.naccept[wi] += 1u;
+                                     }
+                                 });
+                    __syncthreads();                                  // the teams' slots become rows again; the settled walkers are in place
+                    if (threadIdx.x == 0 && stat) { stat[1] += 10ull * (wall_clock64() - t_settle); stat[3] += count; stat[4] += 1ull; }
+                }
+            }
+        }
+    }
+    flush_lazy();
+}
+
+hipError_t launch_chain(int ndim, int nchains, const ChainArgs& a, hipStream_t st)
+{
+    switch (ndim) {
+    case 7: hipLaunchKernelGGL(k_stretch_chain<7>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+    case 12: hipLaunchKernelGGL(k_stretch_chain<12>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_stretch_chain<0>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
 // Ensemble mean of every stored step: chain [nchains][cap][nwalkers][ndim] -> mean [nchains][nstored][ndim]
 // (the series emcee's acor works on, golemflavor/mcmc.py:45-51).  One block per (step, chain); thread t sums
 // the elements t, t + 256, ... of the step's contiguous nwalkers x ndim block whose column is (t mod ndim)
@@ -572,6 +947,10 @@ struct gf_sampler {
     GfArbQueue* d_pq = nullptr;         // BSM posteriors: proposals parked for k_stretch_settle (capacity: one half-step's proposals)
     double* d_pend_rows = nullptr;      // [nchains * nwalkers / 2][GF_PEND_STRIDE]
     unsigned int* d_pend_ctl = nullptr; // [nchains * nwalkers / 2][2]: k_stretch_settle's per-walker counters, zero between uses
+    double* d_lazy_rows = nullptr;      // k_stretch_chain: [nchains][lazy_cap][GF_PEND_STRIDE], undecided proposals that are rejected either way
+    unsigned long long* d_lazy_mask = nullptr;   // [nchains][lazy_cap]
+    int lazy_cap = 0;
+    unsigned long long* d_chain_stats = nullptr;   // [nchains][8]: k_stretch_chain's per-chain census (ChainArgs::stats), zeroed by gf_sampler_reset
     double* d_chain = nullptr;
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
@@ -710,6 +1089,9 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_pq) (void)hipFree(s->d_pq);
     if (s->d_pend_rows) (void)hipFree(s->d_pend_rows);
     if (s->d_pend_ctl) (void)hipFree(s->d_pend_ctl);
+    if (s->d_lazy_rows) (void)hipFree(s->d_lazy_rows);
+    if (s->d_lazy_mask) (void)hipFree(s->d_lazy_mask);
+    if (s->d_chain_stats) (void)hipFree(s->d_chain_stats);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     for (int i = 0; i < gf_sampler::FLIGHT; ++i) if (s->flight_ev[i]) (void)hipEventDestroy(s->flight_ev[i]);
@@ -834,6 +1216,7 @@ int gf_sampler_reset(gf_sampler* s)
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
     GFS_HIP(hipMemsetAsync(s->d_naccept, 0, sizeof(uint32_t) * (size_t)s->nchains * s->nwalkers, (hipStream_t)stream));
     GFS_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(uint32_t) * 4, (hipStream_t)stream));
+    if (s->d_chain_stats) GFS_HIP(hipMemsetAsync(s->d_chain_stats, 0, sizeof(unsigned long long) * 8 * (size_t)s->nchains, (hipStream_t)stream));
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
     s->nstored = 0;
     s->steps_since_reset = 0;
@@ -1024,6 +1407,57 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             return GF_OK;
         }
     }
+    // BSM posteriors on ensembles of up to 1024 walkers: one workgroup per chain, a block of steps per launch, parked proposals
+    // settled inside the chain's own workgroup (k_stretch_chain) -- chains that park nothing never wait for one that does
+    {
+        const char* env = gf_internal_env("GF_SAMPLER_CHAIN", 0);              // "0": always the per-half-step grid kernels (A/B, tests)
+        if (c->mode == MODE_BSM_GAUSS && s->nwalkers / 2 <= 512 && !(env && env[0] == '0')) {
+            if (!s->d_lazy_rows) {
+                // room for the proposals whose verdict only the count waits for: at least two passes' worth per chain, ~64 MB in all
+                const int pass = s->nwalkers / 2 < CH_BLOCK ? s->nwalkers / 2 : CH_BLOCK;
+                int64_t cap = ((int64_t)64 << 20) / ((int64_t)s->nchains * (int64_t)(sizeof(double) * GF_PEND_STRIDE + 8));
+                if (cap > 1024) cap = 1024;
+                if (cap < 2 * pass) cap = 2 * pass;
+                GFS_HIP(hipMalloc((void**)&s->d_lazy_rows, sizeof(double) * GF_PEND_STRIDE * (size_t)cap * s->nchains));
+                {
+                    hipError_t e_ = hipMalloc((void**)&s->d_lazy_mask, sizeof(unsigned long long) * (size_t)cap * s->nchains);
+                    if (e_ != hipSuccess) { (void)hipFree(s->d_lazy_rows); s->d_lazy_rows = nullptr; return sfail(e_, "hipMalloc(lazy list)"); }
+                }
+                s->lazy_cap = (int)cap;
+                if (hipMalloc((void**)&s->d_chain_stats, sizeof(unsigned long long) * 8 * (size_t)s->nchains) == hipSuccess)
+                    (void)hipMemsetAsync(s->d_chain_stats, 0, sizeof(unsigned long long) * 8 * (size_t)s->nchains, st);
+                else { s->d_chain_stats = nullptr; (void)hipGetLastError(); }
+            }
+            ChainArgs ca;
+            ca.lazy_rows = s->d_lazy_rows; ca.lazy_mask = s->d_lazy_mask; ca.lazy_cap = s->lazy_cap;
+            ca.stats = s->d_chain_stats;
+            ca.commons = s->d_commons; ca.tbs = s->models ? s->d_tbs : nullptr; ca.tb = tb; ca.ptabs = s->d_ptabs;
+            ca.nmodels = s->models ? s->nchains : 1; ca.nwalkers = s->nwalkers;
+            ca.pos = s->d_pos; ca.lnp = s->d_lnp; ca.naccept = s->d_naccept; ca.flags = s->d_flags; ca.pend_rows = s->d_pend_rows;
+            ca.chain = store ? s->d_chain : nullptr; ca.lnp_chain = store ? s->d_lnp_chain : nullptr;
+            ca.nstore_cap = s->nstore_cap; ca.store_base = s->nstored; ca.seed = s->seed; ca.thin = thin; ca.store = store ? 1 : 0;
+            ca.a = s->a; ca.stream_ids = s->d_stream_ids;
+            constexpr int64_t CHAIN_STEPS = 16;                                  // steps per launch: the granule of the overlapped read-back
+            int64_t done_c = 0;
+            while (done_c < nsteps) {
+                const int64_t count = nsteps - done_c < CHAIN_STEPS ? nsteps - done_c : CHAIN_STEPS;
+                hipError_t e = flight_admit(s);
+                if (e != hipSuccess) return sfail(e, "block in flight");
+                ca.iteration_base = s->iteration + (uint64_t)done_c;
+                ca.run_step_base = done_c;
+                ca.nsteps = (int32_t)count;
+                e = launch_chain(s->ndim, s->nchains, ca, st);
+                if (e != hipSuccess) return sfail(e, "chain launch");
+                done_c += count;
+                e = flight_mark(s, st, store ? s->nstored + (done_c + thin - 1) / thin : s->nstored);
+                if (e != hipSuccess) return sfail(e, "hipEventRecord");
+            }
+            s->iteration += (uint64_t)nsteps;
+            s->steps_since_reset += nsteps;
+            if (store) s->nstored += (nsteps + thin - 1) / thin;
+            return GF_OK;
+        }
+    }
     constexpr int GRAPH_STEPS = 16;
     int64_t done = 0;
     const bool no_graph = gf_internal_env("GF_SAMPLER_NO_GRAPH", 0) != nullptr;          // diagnostics, read per run
@@ -1126,6 +1560,19 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     if (sink.rc != GF_OK) return sink.rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return sfail(e, "gf_sampler_run_to_host");
+    return GF_OK;
+}
+
+// diagnostics (tools/, not part of the ABI): k_stretch_chain's per-chain census since the last reset, out [nchains][8] (ChainArgs::stats);
+// GF_ERR_UNSUPPORTED where the sampler has not run that kernel
+int gf_internal_sampler_chain_stats(gf_sampler* s, unsigned long long* out)
+{
+    if (!s || !out) return GF_ERR_INVALID_ARG;
+    if (!s->d_chain_stats) return GF_ERR_UNSUPPORTED;
+    const GfCommon* c; const GfBsm* tb; const double* ptab; void* stream; int device;
+    if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
+    GFS_HIP(hipMemcpyAsync(out, s->d_chain_stats, sizeof(unsigned long long) * 8 * (size_t)s->nchains, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GF_OK;
 }
 

@@ -341,6 +341,28 @@ class DeviceEnsembleSampler:
         """How many proposals since the last reset a reference run would have died on (fr.py:493-498)."""
         return self._count_nonunitary()
 
+    def chain_stats(self):
+        """Diagnostics: the per-chain census of the one-workgroup-per-chain sampler (k_stretch_chain) since the last reset, a dict of
+        (nchains,) arrays -- seconds spent proposing / settling proposals the chain waited for / settling in bulk, and the counts of
+        such proposals and passes.  None where that kernel has not run."""
+        fn = getattr(self._L, "gf_internal_sampler_chain_stats", None)
+        if fn is None:
+            return None
+        out = np.zeros((self.nchains, 8), dtype=np.uint64)
+        fn.restype, fn.argtypes = self._C.c_int, [self._C.c_void_p, self._C.POINTER(self._C.c_uint64)]
+        if fn(self._h, out.ctypes.data_as(self._C.POINTER(self._C.c_uint64))) != 0:
+            return None
+        return {"propose_s": out[:, 0] * 1e-9, "settle_s": out[:, 1] * 1e-9, "bulk_s": out[:, 2] * 1e-9, "waited_for": out[:, 3],
+                "passes_that_waited": out[:, 4], "settled_in_bulk": out[:, 5], "passes": out[:, 6], "bulk_settlements": out[:, 7]}
+
+    def undecided_census(self):
+        st = self.chain_stats()
+        if st is None:
+            return None
+        return {"undecided_waited_for": int(st["waited_for"].sum()), "undecided_settled_in_bulk": int(st["settled_in_bulk"].sum()),
+                "chains_that_waited": int(np.count_nonzero(st["waited_for"])),
+                "slowest_chain": {k: (float(v[np.argmax(st["propose_s"] + st["settle_s"] + st["bulk_s"])])) for k, v in st.items()}}
+
     def _check_flags(self):
         # reference behaviour: AssertionError out of test_unitarity kills the run (fr.py:493-498); with
         # on_nonunitary="-inf" the count is only taken when somebody asks for it (`nonunitary_proposals`)

@@ -30,7 +30,7 @@ from . import llh as llh_utils
 from . import mcmc as mcmc_utils
 from .descriptor import compile_model
 from .enums import Texture
-from .model import Model, Prefaulted
+from .model import Model, Prefaulted, empty_hugepages
 
 
 def _patched(template, **fields):
@@ -173,6 +173,23 @@ class _SensPoint:
         return samples
 
 
+_ARENA = {"array": None}
+
+
+def result_array(shape):
+    """Host memory for a scan's result (GBs that a device-to-host copy is about to fill for the first time): backed by 2 MiB pages
+    where the kernel grants them (model.empty_hugepages; GF_SCAN_NO_HUGEPAGES=1: plain np.empty, the A/B of
+    profiles/r04/readback.txt).  GF_SCAN_ARENA=1 (experiments only: a later scan overwrites an earlier one's result): one
+    process-lifetime block, reused, so that the second scan of a process writes into pages that are already mapped."""
+    n = int(np.prod(shape, dtype=np.int64))
+    if os.environ.get("GF_SCAN_ARENA"):
+        a = _ARENA["array"]
+        if a is None or a.size < n:
+            a = _ARENA["array"] = (np.empty(n) if os.environ.get("GF_SCAN_NO_HUGEPAGES") else empty_hugepages((n,)))
+        return a[:n].reshape(shape)
+    return np.empty(shape) if os.environ.get("GF_SCAN_NO_HUGEPAGES") else empty_hugepages(shape)
+
+
 PHASES = {}          # wall-clock seconds of the last run_points call, by phase (reported by main)
 GATHER_STATS = {}     # the last DeviceGather.run: bytes and seconds by phase
 LAST_NONUNITARY = {}  # the last stacked run_points call: proposals the reference would have raised on, and how they were settled
@@ -221,7 +238,10 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         # proposals of the stored run the reference would have died on (fr.py:493-498): rejected on the device, counted here
         LAST_NONUNITARY.clear()
         LAST_NONUNITARY.update({"nonunitary_proposals_rejected": int(sampler.nonunitary_proposals),
-                                "settled": "on the device, before the accept step (k_stretch_settle)"})
+                                "settled": "on the device, before the accept step (k_stretch_chain / k_stretch_settle)"})
+        census = sampler.undecided_census()
+        if census is not None:
+            LAST_NONUNITARY.update(census)
         t0 = time.perf_counter()
         if gather is not None:
             out = gather.run(sampler, jobs, order, len(points), streamed=streamed)
@@ -299,13 +319,14 @@ class DeviceGather:
         self._dest = Prefaulted(shape)
 
     def destination(self, shape):
-        """The prepared array, its pages mapped (waits for the mapping threads), if it has this shape (else None: the callee
-        allocates)."""
+        """Where the result goes: the prepared array, its pages mapped (GF_SCAN_PREFAULT; waits for the mapping threads), if it has
+        this shape, else fresh memory on huge pages (`result_array`)."""
         d, self._dest = self._dest, None
-        if d is None:
-            return None
-        a = d.get()
-        return a if a.shape == tuple(shape) else None
+        if d is not None:
+            a = d.get()
+            if a.shape == tuple(shape):
+                return a
+        return result_array(tuple(shape))
 
     def finish_destination(self):
         pass

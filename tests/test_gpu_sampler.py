@@ -165,6 +165,7 @@ def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
     p0 = np.stack([uniform_theta(ps, 48, rng, seeds=True) for _ in range(3)])
     p0[:, :, 11] = rng.uniform(-52, -40, (3, 48))
     chains = {}
+    monkeypatch.setenv("GF_SAMPLER_CHAIN", "0")                # the per-half-step grid kernels (ensembles this small take k_stretch_chain otherwise)
     for lpw in ("1", "4", "16"):
         monkeypatch.setenv("GF_SAMPLER_LPW", lpw)
         s = mcmc_utils.DeviceEnsembleSampler(48, 12, f, nchains=3, seed=21)
@@ -173,11 +174,57 @@ def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
         chains[lpw] = (s.chain, s.lnprobability, s.acceptance_fraction)
         s.close()
     monkeypatch.delenv("GF_SAMPLER_LPW")
+    monkeypatch.delenv("GF_SAMPLER_CHAIN")
     for lpw in ("4", "16"):
         for x, y in zip(chains["1"], chains[lpw]):
             assert np.array_equal(x, y, equal_nan=True), lpw
     assert np.isfinite(chains["1"][1]).mean() > 0.5 and 0.05 < chains["1"][2].mean() < 0.9
     f.close()
+
+
+@pytest.mark.parametrize("nwalkers,stacked", [(48, False), (64, True), (300, True), (600, False)])
+def test_per_chain_sampler_equals_grid_sampler(monkeypatch, nwalkers, stacked):
+    """Round 4: BSM ensembles of up to 1024 walkers run with ONE WORKGROUP PER CHAIN (k_stretch_chain): a block of steps per
+    launch, half-steps behind a workgroup barrier, and the proposals whose unitarity the in-kernel tiers cannot settle are
+    settled by the chain's own workgroup (28 nine-lane teams) before it goes on -- a chain that parks nothing never waits
+    for one that does.  Same Philox counters, same evaluation, same emulated-x87 chain, same accept rule as the per-half-step
+    grid kernels + k_stretch_settle (GF_SAMPLER_CHAIN=0): chain, lnprob chain, acceptance counters, the count of
+    non-unitary proposals and the final state must be theirs bit for bit -- through texture OEU's failing region (parked
+    proposals in most half-steps), with a half-ensemble smaller than, equal to a fraction of, and larger than one workgroup
+    (600 walkers: two passes per half-step), one posterior for all chains and one per chain, across runs with thinning."""
+    inj = fr_utils.fr_to_angles((1, 1, 1))
+    asimov, ps = Cf.fr_paramsets(6, inj)
+    rng = np.random.default_rng(31)
+    box = np.array(ps.seeds, dtype=float)
+    nch = 3
+    if stacked:
+        fs = [llh_utils.bsm_ln_prob(bsm_args(6, tex, src), asimov, ps, smearing=0.3, on_nonunitary="-inf")
+              for tex, src in ((Texture.OEU, (1 / 3, 2 / 3, 0.)), (Texture.OET, (0., 1., 0.)), (Texture.OUT, (1., 0., 0.)))]
+        post = fs
+    else:
+        fs = [llh_utils.bsm_ln_prob(bsm_args(6, Texture.OEU, (1 / 3, 2 / 3, 0.)), asimov, ps, smearing=0.3, on_nonunitary="-inf")]
+        post = fs[0]
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(nch, nwalkers, 12))
+    p0[:, :, 11] = rng.uniform(-40.0, -30.0, (nch, nwalkers))            # across the top of the scale range: the assert fires there
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GF_SAMPLER_CHAIN", mode)
+        s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 12, post, nchains=nch, seed=5, stream_ids=[7, 2, 40])
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 21, storechain=False)                              # 16 + 5: two launches of the chain kernel
+        nb0 = s.nonunitary_proposals
+        s.reset()
+        s.run_mcmc(None, 35, thin=3)
+        s.run_mcmc(None, 18, thin=3)
+        out[mode] = (s.chain, s.lnprobability, s.acceptance_fraction, np.array([nb0, s.nonunitary_proposals]), s.state[0], s.state[1])
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_CHAIN")
+    for x, y in zip(out["1"], out["0"]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert out["1"][0].shape == (nch, nwalkers, 12 + 6, 12)
+    assert out["1"][3][1] > 20                                            # the chains do live where proposals are parked and rejected
+    for f in fs:
+        f.close()
 
 
 def test_walker_mean_and_acor_on_device(golden):
@@ -271,6 +318,7 @@ def test_graph_replay_equals_eager_launches(monkeypatch):
     p0 = rng.uniform(box[:, 0], box[:, 1], size=(2, 48, 12))
     p0[:, :, 11] = rng.uniform(-30, -24, (2, 48))
     out = {}
+    monkeypatch.setenv("GF_SAMPLER_CHAIN", "0")                # the grid kernels are what a graph replays
     for eager in (False, True):
         if eager:
             monkeypatch.setenv("GF_SAMPLER_NO_GRAPH", "1")
@@ -283,6 +331,7 @@ def test_graph_replay_equals_eager_launches(monkeypatch):
         out[eager] = (s.chain, s.lnprobability, s.acceptance_fraction)
         s.close()
     monkeypatch.delenv("GF_SAMPLER_NO_GRAPH")
+    monkeypatch.delenv("GF_SAMPLER_CHAIN")
     for x, y in zip(out[False], out[True]):
         assert np.array_equal(x, y, equal_nan=True)
     assert out[False][0].shape == (2, 48, 17 + 14, 12)
