@@ -951,6 +951,11 @@ struct gf_sampler {
     unsigned long long* d_lazy_mask = nullptr;   // [nchains][lazy_cap]
     int lazy_cap = 0;
     unsigned long long* d_chain_stats = nullptr;   // [nchains][8]: k_stretch_chain's per-chain census (ChainArgs::stats), zeroed by gf_sampler_reset
+    // launch shape of a BSM sampler on small ensembles: 0 = not decided yet, 1 = one workgroup per chain (k_stretch_chain), 2 = the
+    // per-half-step grid kernels + k_stretch_settle.  Decided at the start of every run of 128 steps or more, by timing a block of 16
+    // steps of each on the sampler's own chains (gf_sampler_run); GF_SAMPLER_CHAIN=0 / 1 forces one
+    int shape = 0;
+    double probe_us[2] = {0.0, 0.0};               // what the decision was taken on: us per block of 16 steps, [0] per chain, [1] grid
     double* d_chain = nullptr;
     double* d_lnp_chain = nullptr;
     int64_t nstore_cap = 0, nstored = 0;
@@ -1407,11 +1412,48 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             return GF_OK;
         }
     }
-    // BSM posteriors on ensembles of up to 1024 walkers: one workgroup per chain, a block of steps per launch, parked proposals
-    // settled inside the chain's own workgroup (k_stretch_chain) -- chains that park nothing never wait for one that does
-    {
-        const char* env = gf_internal_env("GF_SAMPLER_CHAIN", 0);              // "0": always the per-half-step grid kernels (A/B, tests)
-        if (c->mode == MODE_BSM_GAUSS && s->nwalkers / 2 <= 512 && !(env && env[0] == '0')) {
+    // BSM posteriors on ensembles of up to 1024 walkers have two launch shapes with the same chain, bit for bit:
+    //   per chain   one workgroup owns a chain for a block of 16 steps and settles its own parked proposals (k_stretch_chain): a chain that
+    //               parks nothing never waits for one that does -- 21 us per half-step where nothing is parked (C5: 256 x 512 walkers);
+    //   grid        one launch per half-step for all chains + k_stretch_settle on the whole GPU (round 3): every chain waits for the
+    //               slowest parked proposal, but a chain that parks TEN proposals per half-step (the top-scale grid points of C5) gets
+    //               3 584 teams for them instead of its workgroup's 56 -- 115 us per half-step against 150.
+    // Which is faster depends on where the chains live NOW (a burn-in that starts below the failing region and drifts into it parks
+    // nothing at first), so every run of 128 steps or more times one block of each shape on its own chains at its start (the second
+    // block of two, the first warms the kernel up; the blocks are the run's own steps, nothing is computed twice) and takes the faster
+    // for the rest of the run; shorter runs take the last decision (none yet: per chain).  GF_SAMPLER_CHAIN=1 / 0 forces a shape.
+    int64_t done = 0;
+    const bool small_bsm = c->mode == MODE_BSM_GAUSS && s->nwalkers / 2 <= 512;
+    constexpr int64_t CHAIN_STEPS = 16;                                  // steps per launch: the granule of the overlapped read-back
+    ChainArgs ca = {};
+    auto chain_block = [&](int64_t count) -> int {                       // `count` steps from `done` on, one launch
+        hipError_t e = flight_admit(s);
+        if (e != hipSuccess) return sfail(e, "block in flight");
+        ca.iteration_base = s->iteration + (uint64_t)done;
+        ca.run_step_base = done;
+        ca.nsteps = (int32_t)count;
+        e = launch_chain(s->ndim, s->nchains, ca, st);
+        if (e != hipSuccess) return sfail(e, "chain launch");
+        done += count;
+        e = flight_mark(s, st, store ? s->nstored + (done + thin - 1) / thin : s->nstored);
+        if (e != hipSuccess) return sfail(e, "hipEventRecord");
+        return GF_OK;
+    };
+    auto grid_block = [&](int count) -> int {                            // the same with the grid kernels, launched one by one
+        hipError_t e = flight_admit(s);
+        if (e != hipSuccess) return sfail(e, "block in flight");
+        e = steps(count);
+        if (e != hipSuccess) return sfail(e, "stretch launch");
+        done += count;
+        e = flight_mark(s, st, store ? hs.store_base + (done + thin - 1) / thin : hs.store_base);
+        if (e != hipSuccess) return sfail(e, "hipEventRecord");
+        return GF_OK;
+    };
+    if (small_bsm) {
+        const char* env = gf_internal_env("GF_SAMPLER_CHAIN", 0);
+        const bool forced = env && (env[0] == '0' || env[0] == '1');
+        int shape = forced ? (env[0] == '0' ? 2 : 1) : (nsteps >= 8 * CHAIN_STEPS ? 0 : s->shape);
+        if (shape != 2) {
             if (!s->d_lazy_rows) {
                 // room for the proposals whose verdict only the count waits for: at least two passes' worth per chain, ~64 MB in all
                 const int pass = s->nwalkers / 2 < CH_BLOCK ? s->nwalkers / 2 : CH_BLOCK;
@@ -1428,7 +1470,6 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
                     (void)hipMemsetAsync(s->d_chain_stats, 0, sizeof(unsigned long long) * 8 * (size_t)s->nchains, st);
                 else { s->d_chain_stats = nullptr; (void)hipGetLastError(); }
             }
-            ChainArgs ca;
             ca.lazy_rows = s->d_lazy_rows; ca.lazy_mask = s->d_lazy_mask; ca.lazy_cap = s->lazy_cap;
             ca.stats = s->d_chain_stats;
             ca.commons = s->d_commons; ca.tbs = s->models ? s->d_tbs : nullptr; ca.tb = tb; ca.ptabs = s->d_ptabs;
@@ -1437,20 +1478,32 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             ca.chain = store ? s->d_chain : nullptr; ca.lnp_chain = store ? s->d_lnp_chain : nullptr;
             ca.nstore_cap = s->nstore_cap; ca.store_base = s->nstored; ca.seed = s->seed; ca.thin = thin; ca.store = store ? 1 : 0;
             ca.a = s->a; ca.stream_ids = s->d_stream_ids;
-            constexpr int64_t CHAIN_STEPS = 16;                                  // steps per launch: the granule of the overlapped read-back
-            int64_t done_c = 0;
-            while (done_c < nsteps) {
-                const int64_t count = nsteps - done_c < CHAIN_STEPS ? nsteps - done_c : CHAIN_STEPS;
-                hipError_t e = flight_admit(s);
-                if (e != hipSuccess) return sfail(e, "block in flight");
-                ca.iteration_base = s->iteration + (uint64_t)done_c;
-                ca.run_step_base = done_c;
-                ca.nsteps = (int32_t)count;
-                e = launch_chain(s->ndim, s->nchains, ca, st);
-                if (e != hipSuccess) return sfail(e, "chain launch");
-                done_c += count;
-                e = flight_mark(s, st, store ? s->nstored + (done_c + thin - 1) / thin : s->nstored);
-                if (e != hipSuccess) return sfail(e, "hipEventRecord");
+        }
+        if (shape == 0 && !forced && nsteps >= 8 * CHAIN_STEPS) {
+            // the probe: two blocks per chain, two blocks on the grid, the second of each timed
+            double us[2] = {0.0, 0.0};
+            for (int which = 0; which < 2; ++which)
+                for (int rep = 0; rep < 2; ++rep) {
+                    GFS_HIP(hipStreamSynchronize(st));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    int rc = GF_OK;
+                    if (which == 0) {
+                        rc = chain_block(CHAIN_STEPS);
+                        if (rc == GF_OK) { hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, s->d_state, (int)CHAIN_STEPS); if (hipGetLastError() != hipSuccess) rc = GF_ERR_HIP; }
+                    } else {
+                        rc = grid_block((int)CHAIN_STEPS);
+                    }
+                    if (rc != GF_OK) return rc;
+                    GFS_HIP(hipStreamSynchronize(st));
+                    if (rep == 1) us[which] = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                }
+            s->probe_us[0] = us[0]; s->probe_us[1] = us[1];
+            shape = s->shape = us[0] <= us[1] ? 1 : 2;
+        }
+        if (shape != 2) {                                                  // per chain (also: not decided, and the run too short to probe)
+            while (done < nsteps) {
+                const int rc = chain_block(nsteps - done < CHAIN_STEPS ? nsteps - done : CHAIN_STEPS);
+                if (rc != GF_OK) return rc;
             }
             s->iteration += (uint64_t)nsteps;
             s->steps_since_reset += nsteps;
@@ -1459,7 +1512,6 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         }
     }
     constexpr int GRAPH_STEPS = 16;
-    int64_t done = 0;
     const bool no_graph = gf_internal_env("GF_SAMPLER_NO_GRAPH", 0) != nullptr;          // diagnostics, read per run
     if (!no_graph && nsteps >= 2 * GRAPH_STEPS) {
         // launch-bound inner loop -> hipGraph: capture GRAPH_STEPS steps once, replay
@@ -1573,6 +1625,15 @@ int gf_internal_sampler_chain_stats(gf_sampler* s, unsigned long long* out)
     if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
     GFS_HIP(hipMemcpyAsync(out, s->d_chain_stats, sizeof(unsigned long long) * 8 * (size_t)s->nchains, hipMemcpyDeviceToHost, (hipStream_t)stream));
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GF_OK;
+}
+
+// diagnostics (not part of the ABI): out[0] = the launch shape of a small-ensemble BSM sampler (0 undecided, 1 per chain, 2 grid),
+// out[1], out[2] = the probe's us per block of 16 steps, per chain / grid (0 when it has not run)
+int gf_internal_sampler_shape(const gf_sampler* s, double out[3])
+{
+    if (!s || !out) return GF_ERR_INVALID_ARG;
+    out[0] = (double)s->shape; out[1] = s->probe_us[0]; out[2] = s->probe_us[1];
     return GF_OK;
 }
 

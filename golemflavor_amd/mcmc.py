@@ -355,6 +355,19 @@ class DeviceEnsembleSampler:
         return {"propose_s": out[:, 0] * 1e-9, "settle_s": out[:, 1] * 1e-9, "bulk_s": out[:, 2] * 1e-9, "waited_for": out[:, 3],
                 "passes_that_waited": out[:, 4], "settled_in_bulk": out[:, 5], "passes": out[:, 6], "bulk_settlements": out[:, 7]}
 
+    def launch_shape(self):
+        """Diagnostics: how a BSM sampler on small ensembles launches its steps -- {"shape": "per chain" | "grid" | "undecided",
+        "probe_us_per_16_steps": {"per chain": .., "grid": ..}} -- decided at the start of every run of 128 steps or more by timing a block of
+        each on its own chains (gf_sampler_run); GF_SAMPLER_CHAIN=1 / 0 forces one.  The chain is the same bit for bit either way."""
+        fn = getattr(self._L, "gf_internal_sampler_shape", None)
+        if fn is None:
+            return None
+        out = (self._C.c_double * 3)()
+        fn.restype, fn.argtypes = self._C.c_int, [self._C.c_void_p, self._C.POINTER(self._C.c_double)]
+        if fn(self._h, out) != 0:
+            return None
+        return {"shape": ("undecided", "per chain", "grid")[int(out[0])], "probe_us_per_16_steps": {"per chain": float(out[1]), "grid": float(out[2])}}
+
     def undecided_census(self):
         st = self.chain_stats()
         if st is None:

@@ -242,6 +242,9 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         census = sampler.undecided_census()
         if census is not None:
             LAST_NONUNITARY.update(census)
+        shape = sampler.launch_shape()
+        if shape is not None:
+            LAST_NONUNITARY["launch_shape"] = shape
         t0 = time.perf_counter()
         if gather is not None:
             out = gather.run(sampler, jobs, order, len(points), streamed=streamed)

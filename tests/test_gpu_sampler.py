@@ -227,6 +227,46 @@ def test_per_chain_sampler_equals_grid_sampler(monkeypatch, nwalkers, stacked):
         f.close()
 
 
+def test_launch_shape_is_probed_and_never_changes_the_chain(monkeypatch):
+    """A BSM sampler on small ensembles has two launch shapes (one workgroup per chain; per-half-step grid kernels) whose speed
+    depends on where the chains live; with no GF_SAMPLER_CHAIN in the environment every run of 128 steps or more times a block of
+    each on the sampler's own chains at its start and takes the faster one; shorter runs take the last decision.  Whatever it
+    picks, and through the probe itself -- blocks of one shape, then the other, then the rest -- the chain is the forced
+    shapes' chain, bit for bit."""
+    inj = fr_utils.fr_to_angles((1, 1, 1))
+    asimov, ps = Cf.fr_paramsets(6, inj)
+    f = llh_utils.bsm_ln_prob(bsm_args(6, Texture.OEU, (1 / 3, 2 / 3, 0.)), asimov, ps, smearing=0.3, on_nonunitary="-inf")
+    rng = np.random.default_rng(9)
+    box = np.array(ps.seeds, dtype=float)
+    p0 = rng.uniform(box[:, 0], box[:, 1], size=(4, 64, 12))
+    p0[:, :, 11] = rng.uniform(-40.0, -30.0, (4, 64))
+    out = {}
+    for mode in ("auto", "1", "0"):
+        if mode == "auto":
+            monkeypatch.delenv("GF_SAMPLER_CHAIN", raising=False)
+        else:
+            monkeypatch.setenv("GF_SAMPLER_CHAIN", mode)
+        s = mcmc_utils.DeviceEnsembleSampler(64, 12, f, nchains=4, seed=3)
+        s.on_nonunitary = "-inf"
+        s.run_mcmc(p0, 30, storechain=False)                              # too short to probe: per chain, undecided
+        shape0 = s.launch_shape()
+        s.run_mcmc(None, 130, thin=2)                                     # probed here (auto)
+        shape1 = s.launch_shape()
+        s.run_mcmc(None, 40, thin=2)                                      # too short to probe again: the last decision
+        out[mode] = (s.chain, s.lnprobability, s.acceptance_fraction, s.nonunitary_proposals)
+        if mode == "auto":
+            assert shape0["shape"] == "undecided" and shape1["shape"] in ("per chain", "grid")
+            assert min(shape1["probe_us_per_16_steps"].values()) > 0.0
+            assert s.launch_shape() == shape1                              # a short run keeps the decision
+        s.close()
+    monkeypatch.delenv("GF_SAMPLER_CHAIN", raising=False)
+    for other in ("1", "0"):
+        for x, y in zip(out["auto"][:3], out[other][:3]):
+            assert np.array_equal(x, y, equal_nan=True), other
+        assert out["auto"][3] == out[other][3]
+    f.close()
+
+
 def test_walker_mean_and_acor_on_device(golden):
     """mcmc.py:45-51 prints sampler.acor: the ensemble-mean series is reduced on the device."""
     asimov, ps = notebook_sets(golden)
