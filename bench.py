@@ -370,7 +370,7 @@ def device_gather_subphase(rccl, device, region, whole, rank, world, control):
     return rec if rank == 0 else None
 
 
-def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rccl=None, rccl_init_s=None, shared=False):
+def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rccl=None, rccl_init_s=None, shared=False, arena=None):
     """C4 / C5 end to end at full size, the grid sharded over the ranks -- golemflavor_amd.scan's own code path: stacked device
     sampler per rank, post-processing (C4), and the delivery: `shared` (the ranks are on one node): every rank reads its own
     chains back over its own PCIe link into one host segment rank 0 maps too (scan.SharedHostGather), with the device gather
@@ -385,7 +385,7 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
     t0 = time.perf_counter()
     chains, gather_kind, local, g = None, None, {}, None
     if world > 1 and shared:
-        g = scan.SharedHostGather(control, rank, world)
+        g = scan.SharedHostGather(control, rank, world, arena=arena)
         chains = scan.run_points(pts, mine, make, burnin, nsteps, stacked=True, gather=g)
         local = dict(scan.PHASES)
         local.update({k: v for k, v in g.stats.items() if isinstance(v, (int, float)) and k not in ("ranks", "slots_per_rank")})
@@ -442,6 +442,38 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
         rec["device_gather_subphase"] = sub
     if isinstance(g, scan.SharedHostGather):
         g.release()
+    return rec
+
+
+def extra_c5_sampler(device, burnin=100, nsteps=200):
+    """The C5 scan's SAMPLING alone (256 chains x 512 walkers of the 12-column posterior, chain kept on the device): what the device
+    sampler delivers where nothing hides behind a read-back.  With the launch shape it chose (one workgroup per chain, or per-half-step
+    grid kernels: mcmc.DeviceEnsembleSampler.launch_shape), the census of undecided proposals, and the fraction of the fp64 issue
+    rate that arrives as posterior evaluations (the evaluation's own VALU count per walker from profiles/bsm_instr.json -- the
+    emulated-x87 settling of undecided proposals is not counted as useful work)."""
+    from golemflavor_amd import mcmc as mcmc_utils
+    pts, nw, make, evals = scan_setup("C5", device)
+    jobs = [make(p, g) for g, p in enumerate(pts)]
+    smp = mcmc_utils.DeviceEnsembleSampler(nw, 12, [j.f for j in jobs], seed=25, stream_ids=list(range(len(jobs))))
+    smp.on_nonunitary = "-inf"
+    t0 = time.perf_counter()
+    smp.run_mcmc(np.stack([j.p0 for j in jobs]), burnin, storechain=False)
+    t1 = time.perf_counter()
+    smp.reset()
+    smp.run_mcmc(None, nsteps)
+    t2 = time.perf_counter()
+    n_eval = len(pts) * nw * nsteps
+    rec = {"workload": "C5 sampling only: %d chains x %d walkers, %d burn-in + %d stored steps, chain kept on the device" % (len(pts), nw, burnin, nsteps),
+           "burnin_s": t1 - t0, "stored_run_s": t2 - t1, "seconds": t2 - t0, "us_per_half_step_stored_run": 1e6 * (t2 - t1) / (2 * nsteps),
+           "evals_per_s_stored_run": n_eval / (t2 - t1), "launch_shape": smp.launch_shape(), "undecided": smp.undecided_census(),
+           "nonunitary_proposals": int(smp.nonunitary_proposals)}
+    ipw = ((_profile_constants() or {}).get("12_no_status", {}) or {}).get("valu_wave_instr_per_walker")
+    if ipw:
+        rec["valu_instr_per_walker"] = ipw
+        rec["fp64_issue_fraction"] = (n_eval / 64.0) * ipw / (t2 - t1) / FP64_ISSUE_PER_S
+    smp.close()
+    for j in jobs:
+        j.close()
     return rec
 
 
@@ -605,7 +637,7 @@ def run(a, json_out):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     L = _lib.lib()                           # libgolemhip.so (and with it /opt/rocm's runtime + librccl) before anything else ROCm
     control = gdist.SocketBackend(rank, world) if world > 1 else gdist.LocalBackend()
-    rccl, rccl_error, stuck, rccl_init_s, shared = None, None, False, None, False
+    rccl, rccl_error, stuck, rccl_init_s, shared, arena, host_segment = None, None, False, None, False, None, None
     ps, bf, desc = notebook_descriptor()
     if world > 1:
         # RCCL communicator of the library itself; its unique id travels over the socket control plane.  The timed
@@ -617,8 +649,22 @@ def run(a, json_out):
         rccl, rccl_error, stuck = gdist.open_device_gather(rank, world, local_rank, control,
                                                            timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
         rccl_init_s = float(control.allreduce_max([time.perf_counter() - t_r])[0])
-        # one node (the contract's case)?  Then the scans deliver over every rank's own PCIe link into one host segment
+        # one node (the contract's case)?  Then the scans deliver over every rank's own PCIe link into one host segment -- created
+        # HERE, once, for both scans: its 4 KiB shmem pages are allocated (and zeroed) by rank 0 at 17 GB/s at best, i.e. 0.7 s for
+        # the C5 result, which no scan could hide; beside the job's start-up it costs nothing (reported as `host_segment`)
         shared = gdist.same_node(control) and not os.environ.get("GF_SCAN_DEVICE_GATHER")
+        if shared and not a.no_extras:
+            from golemflavor_amd import scan as _scan
+            t_s = time.perf_counter()
+            need = max(_scan.segment_bytes(64, world, 2048, a.scan_nsteps, 9), _scan.segment_bytes(256, world, 512, a.scan_nsteps, 12))
+            arena = gdist.HostSegment(control, need)
+            seg_create_s = time.perf_counter() - t_s
+            arena.wait_allocated()                 # (rank 0: the background posix_fallocate; done before anything is timed)
+            control.barrier()
+            host_segment = {"bytes": int(need), "kind": arena.kind, "error": arena.error, "create_and_map_s": round(seg_create_s, 4),
+                            "allocate_s": round(float(control.allreduce_max([time.perf_counter() - t_s])[0]), 4),
+                            "note": "one host segment for the job's scans, created and allocated (posix_fallocate, rank 0) before the timed "
+                                    "region; every scan's result goes into it, every rank through its own PCIe link"}
         # fixed physics constants: rank 0's packed descriptor is the one everybody uses
         desc = gdist.broadcast_descriptors([desc] if rank == 0 else [], rccl if getattr(rccl, "kind", None) == "rccl" else control)[0]
 
@@ -706,9 +752,12 @@ def run(a, json_out):
             guarded("c5_bulk", lambda: extra_bulk(local_rank, Cf.fr_paramsets(6, (0.4444, 0.0))[1], "C5"))
             guarded("c4_scan", lambda: extra_scan(local_rank, "C4", 100, 200))
             guarded("c5_scan", lambda: extra_scan(local_rank, "C5", 100, 200))
+            guarded("c5_sampler", lambda: extra_c5_sampler(local_rank))
         for key, cfg in (("c4_scan_ref", "C4"), ("c5_scan_ref", "C5")):
             guarded(key, lambda cfg=cfg: extra_scan(local_rank, cfg, a.scan_burnin, a.scan_nsteps, rank, world, control, rccl,
-                                                    rccl_init_s, shared), collective=True)
+                                                    rccl_init_s, shared, arena), collective=True)
+        if host_segment is not None:
+            extras["host_segment"] = host_segment
 
     if rank == 0:
         cb, parity = None, None

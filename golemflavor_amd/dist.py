@@ -84,6 +84,7 @@ class HostSegment:
         import secrets
         self.nbytes, self.buffer, self.error, self.kind = int(nbytes), None, None, None
         self._mm = None
+        self._alloc_thread = None
         rank, err, fd, path = control.rank, "", -1, ""
         if rank == root:
             try:
@@ -98,6 +99,27 @@ class HostSegment:
                     path = "/proc/%d/fd/%d" % (os.getpid(), fd)
                     self.kind = "memfd"
                 os.ftruncate(fd, max(self.nbytes, 1))
+                # The segment's pages are 4 KiB shmem pages (transparent huge pages are off for shmem on the MI355X boxes) and have to
+                # be allocated and zeroed before anybody can write them: from the read-back's copy threads, fault by fault, that ran
+                # at 1.8 GB/s per rank; posix_fallocate from ONE thread does 17 GB/s, more threads only contend (tools/
+                # shm_fault_probe.py, profiles/r04/shm_pages.txt).  So the root allocates the file in the background, from here on --
+                # behind the sampling for a scan that has one; a writer that gets ahead of it just takes the slow path for a while.
+                if self.nbytes >= (64 << 20) and not os.environ.get("GF_SEGMENT_NO_FALLOCATE"):
+                    import threading
+                    fd2 = os.dup(fd)
+
+                    def _allocate(fd2=fd2, n=self.nbytes):
+                        try:
+                            step = 1 << 30
+                            for off in range(0, n, step):
+                                os.posix_fallocate(fd2, off, min(step, n - off))
+                        except OSError:
+                            pass
+                        finally:
+                            os.close(fd2)
+
+                    self._alloc_thread = threading.Thread(target=_allocate, daemon=True)
+                    self._alloc_thread.start()
             except Exception as exc:       # noqa: BLE001
                 err = "%s: %s" % (type(exc).__name__, exc)
         meta = control.broadcast_bytes(("%s\n%s\n%s" % (err, path, self.kind or "")).encode() if rank == root else b"", root).decode()
@@ -133,8 +155,15 @@ class HostSegment:
         n = int(np.prod(shape, dtype=np.int64))
         return np.frombuffer(self._mm, dtype=dtype, count=n, offset=int(offset)).reshape(shape)
 
+    def wait_allocated(self):
+        """(root) Join the background allocation of the segment's pages; returns at once elsewhere."""
+        t, self._alloc_thread = self._alloc_thread, None
+        if t is not None:
+            t.join()
+
     def close(self):
         """Unmap (a rank that holds views keeps the pages until they are gone: the mapping is closed by the last reference)."""
+        self.wait_allocated()
         mm, self._mm, self.buffer = self._mm, None, None
         if mm is not None:
             try:

@@ -439,10 +439,16 @@ class SharedHostGather:
 
     kind = "shared host segment"
 
-    def __init__(self, control, rank, world, root=0):
+    def __init__(self, control, rank, world, root=0, arena=None):
+        """arena: a `dist.HostSegment` that outlives this scan (every rank passes its own handle of the same segment, or every
+        rank None).  The pages of a shared segment are 4 KiB shmem pages that somebody has to allocate and zero -- 17 GB/s at
+        best on the MI355X boxes (profiles/r04/shm_pages.txt), less than ONE PCIe link delivers -- so a job that runs more than one
+        scan, or has anything to do before its scan, creates the segment once, ahead of time (bench.py: beside the RCCL
+        bootstrap), and every scan whose result fits uses it; the result of an earlier scan is overwritten by the next."""
         self.control, self.rank, self.world, self.root = control, int(rank), int(world), int(root)
         self.rccl = None
         self.stats = {}
+        self.arena = arena
         self.seg, self.region, self._all = None, None, None
         self.readback_tail_s = 0.0
 
@@ -457,7 +463,11 @@ class SharedHostGather:
         slots = gdist.slots_per_rank(n_points, self.world)
         self._geom = (slots, per, width, n_local, n_points)
         t0 = time.perf_counter()
-        self.seg = gdist.HostSegment(self.control, self.world * slots * per * width * 8, root=self.root)
+        need = self.world * slots * per * width * 8
+        if self.arena is not None and self.arena.error is None and self.arena.nbytes >= need:
+            self.seg = self.arena                  # (sizes are a function of the grid: every rank takes this branch or none does)
+        else:
+            self.seg = gdist.HostSegment(self.control, need, root=self.root)
         if self.seg.error is None:
             self._all = self.seg.array((self.world, slots, per, width))
             self.region = self._all[self.rank]
@@ -467,7 +477,16 @@ class SharedHostGather:
 
     def destination(self, shape):
         """This rank's region, shaped as the callee wants it: (n_local, nsteps, nwalkers, ndim) for the streamed chain,
-        (n_local, per, width) for post-processed rows."""
+        (n_local, per, width) for post-processed rows.  Collective the first time: the read-back starts once the segment's pages
+        exist (rank 0's background posix_fallocate: a copy into pages that are still being allocated takes a fault per 4 KiB AND
+        fights the allocation for the file's locks -- 1.2 s instead of 0.25 s for C4's 9.4 GB on two ranks)."""
+        if not getattr(self, "_allocated", False):
+            self._allocated = True
+            if self._all is not None:
+                t0 = time.perf_counter()
+                self.seg.wait_allocated()
+                self.control.barrier()
+                self.allocation_wait_s = time.perf_counter() - t0
         slots, per, width, n_local, _ = self._geom
         assert int(np.prod(shape)) == n_local * per * width, (shape, self._geom)
         return self.region[:n_local].reshape(shape)
@@ -496,8 +515,9 @@ class SharedHostGather:
         nbytes = n_local * per * width * 8
         self.stats.update({"ranks": self.world, "slots_per_rank": slots, "pack_s": 0.0, "xgmi_s": 0.0, "gather_bytes": 0,
                            "d2h_s": d2h_s, "d2h_bytes": int(nbytes), "block_bytes": int(nbytes), "segment_s": self.segment_s,
-                           "delivery": ("shared host segment (%s): every rank reads its own chains back over its own PCIe link"
-                                        % self.seg.kind) if self._all is not None else
+                           "segment_allocation_wait_s": float(getattr(self, "allocation_wait_s", 0.0)),
+                           "delivery": ("shared host segment (%s%s): every rank reads its own chains back over its own PCIe link"
+                                        % (self.seg.kind, ", created ahead of the scan" if self.seg is self.arena else "")) if self._all is not None else
                                        "private read-back, blocks to rank 0 over the control plane (no shared segment: %s)" % self.seg.error})
         if note:
             self.stats["note"] = note
@@ -517,9 +537,14 @@ class SharedHostGather:
         """Drop this object's views of the segment and unmap it (the arrays `run` handed out on rank 0 keep the pages for as long
         as they live)."""
         self._all = self.region = None
-        if self.seg is not None:
+        if self.seg is not None and self.seg is not self.arena:
             self.seg.close()
-            self.seg = None
+        self.seg = None
+
+
+def segment_bytes(n_points, world, nwalkers, nsteps, width):
+    """Bytes of the host segment a `SharedHostGather` needs for a grid of n_points on `world` ranks."""
+    return world * gdist.slots_per_rank(n_points, world) * nsteps * nwalkers * width * 8
 
 
 def finite_fraction(arrays, stride_target=4096):
@@ -585,8 +610,14 @@ def main(argv=None):
     want_gather = (not a.datadir) or bool(a.outfile)
     force_device = bool(os.environ.get("GF_SCAN_RCCL")) or bool(os.environ.get("GF_SCAN_DEVICE_GATHER"))
     shared = False
+    arena = None
     if world > 1 and want_gather and can_deliver and not force_device:
         shared = gdist.same_node(control)
+        if shared:
+            # created FIRST: rank 0 allocates its pages in the background (17 GB/s at best for 4 KiB shmem pages) while every rank
+            # compiles its models, burns in and samples
+            width = 9 if a.config == "C4" else 12
+            arena = gdist.HostSegment(control, segment_bytes(len(pts), world, nw, a.nsteps, width))
     rccl, rccl_err, stuck = None, None, False
     if want_gather and not shared and (world > 1 or os.environ.get("GF_SCAN_RCCL")):
         rccl, rccl_err, stuck = gdist.open_device_gather(rank, world, device, control, timeout=float(os.environ.get("GF_RCCL_TIMEOUT", "60")))
@@ -596,7 +627,7 @@ def main(argv=None):
         local = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=stacked)
         gather_name = "none: every rank saved its own files (--datadir)"
     elif shared:
-        g = SharedHostGather(control, rank, world)
+        g = SharedHostGather(control, rank, world, arena=arena)
         chains = run_points(pts, mine, make, a.burnin, a.nsteps, stacked=True, gather=g)
         gather_name = g.stats.get("delivery", g.kind)
         g.release()
