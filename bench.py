@@ -24,7 +24,7 @@ long-double restatement of the reference, kind "port") timed on this host on a b
 
 After the timed region (`--no-extras` skips them) the other BASELINE configurations are measured too, each bounded to a
 few seconds, as sub-records of the same line.  At every N: `c4_scan_ref` / `c5_scan_ref` -- the full 64 x 2048 and
-256 x 512 grid scans SHARDED over the N ranks (grid point g -> rank g mod N, one stacked device sampler per rank) at the
+256 x 512 grid scans SHARDED over the N ranks (grid point g -> rank (g + g div N) mod N, one stacked device sampler per rank) at the
 reference's own chain length (burnin 200 + 1000 stored steps, submitter/mc_texture_dag.py:33-39), chains gathered to rank 0
 over RCCL / xGMI (`gf_comm_gather`) and downloaded once, reported by phase (`rccl_init_s`, `sampling_s`, `pack_s`,
 `gather_bytes`, `gather_GBps`, `d2h_s`, `ranks`, `evals_per_s`; a fixed grid: these sub-records are STRONG scaling) -- and
@@ -299,7 +299,7 @@ def scan_record_from_phases(config, world, n_points, walkers, burnin, nsteps, ev
     xgmi_s = phases.get("xgmi_s", 0.0)
     gbytes = phases.get("gather_bytes", 0.0)
     rec = {"workload": "%s: %d grid points x %d walkers, %d burn-in + %d stored steps, sharded over %d rank(s) (grid point g -> "
-                       "rank g mod N), one stacked device sampler per rank" % (config, n_points, walkers, burnin, nsteps, world),
+                       "rank (g + g div N) mod N), one stacked device sampler per rank" % (config, n_points, walkers, burnin, nsteps, world),
            "scaling": "strong (a fixed grid divided over the ranks)", "ranks": int(world), "grid_points": int(n_points),
            "walkers": int(walkers), "burnin": int(burnin), "nsteps": int(nsteps), "seconds": float(seconds),
            "evals": int(evals_total), "evals_per_s": evals_total / max(seconds, 1e-12),

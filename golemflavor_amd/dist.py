@@ -2,7 +2,7 @@
 
 The reference's only "distributed" layer is HTCondor: one job per grid point, results as .npy
 files on a shared filesystem (submitter/mc_texture_dag.py:57-71, submitter/sens_dag.py:75-95).
-Here the same partitioning runs inside one node: grid point g belongs to rank g mod world, the
+Here the same partitioning runs inside one node: grid point g belongs to rank (g + g div world) mod world (`owner`), the
 data path has no collective, and only two exchanges exist -- a broadcast of the packed model
 descriptors at start and a gather of the chain blocks at the end.
 
@@ -30,11 +30,27 @@ import numpy as np
 from . import _lib
 
 
+def owner(g, world):
+    """The rank that runs grid point g: (g + g div world) mod world -- round robin with the start moved on by one in every block
+    of `world` points.  Plain g mod world (rounds 1-3) hands a rank every world-th point, and the grids of the scans are
+    products whose fastest axis has `world`-friendly lengths: on 8 ranks ALL 32 top-scale points of the C5 grid (8 scales
+    fastest) -- the chains that sit in the reference's failing region and cost several times the others (profiles/r04/
+    chain_census.txt) -- went to rank 7.  Skewed, every rank gets 4 of them.  Each block of `world` consecutive points still
+    gives every rank exactly one, so a point's slot on its rank stays g div world."""
+    return (g + g // world) % world
+
+
 def shard(n_items, rank, world):
-    """Grid point g -> rank g mod world; returns this rank's points in order."""
+    """This rank's grid points, in order (independent chains, no data-path collective): the points g with
+    `owner(g, world) == rank`, i.e. one per block of `world` points."""
     if not 0 <= rank < world:
         raise ValueError("rank %d outside world of %d" % (rank, world))
-    return list(range(rank, n_items, world))
+    out = []
+    for b in range((n_items + world - 1) // world):
+        g = b * world + ((rank - b) % world)
+        if g < n_items:
+            out.append(g)
+    return out
 
 
 def slots_per_rank(n_items, world):
@@ -740,7 +756,7 @@ def gather_chains(local, n_points, backend, allgather=None):
     for slot, g in enumerate(mine):
         send[slot] = local[g]
     allb = ag(send)                                    # (world, slots, ...)
-    return [np.array(allb[g % backend.world, g // backend.world]) for g in range(n_points)]
+    return [np.array(allb[owner(g, backend.world), g // backend.world]) for g in range(n_points)]
 
 
 def gather_chains_to_root(local, n_points, backend, root=0):

@@ -2,7 +2,7 @@
 posterior of scripts/fr.py / sens.py's scale scan), sharded over one process per GPU.
 
 The reference runs one HTCondor job per grid point (submitter/mc_texture_dag.py:57-71,
-submitter/sens_dag.py:75-95).  Here grid point g runs on rank g mod N (`dist.shard`), and all grid points
+submitter/sens_dag.py:75-95).  Here grid point g runs on rank (g + g div N) mod N (`dist.owner`), and all grid points
 of a rank are stacked into ONE device-resident sampler -- one ensemble per posterior, one launch per
 half-step for all of them.  No collective on the data path.  The results are DELIVERED the way the reference's
 jobs deliver theirs -- N writers, no funnel (golemflavor/mcmc.py:108-126): on one node every rank reads its own chains back
@@ -355,13 +355,17 @@ class DeviceGather:
                 d_recv.free()
             mine = d_send.download(shape[1:], dtype=dtype)
             t1 = time.perf_counter()
-            pts = {r: mine[i] for i, r in enumerate(range(self.rank, self.world * shape[1], self.world))}
-            parts = gdist.gather_chains_to_root(pts, self.world * shape[1], self.control, self.root)
+            npseudo = self.world * shape[1]                 # every slot of every rank as a point of its own
+            pts = {g: mine[b] for b, g in enumerate(gdist.shard(npseudo, self.rank, self.world))}
+            parts = gdist.gather_chains_to_root(pts, npseudo, self.control, self.root)
             self.stats.update(xgmi_s=0.0, d2h_s=t1 - t0, host_gather_s=time.perf_counter() - t1, gather_bytes=0,
                               d2h_bytes=int(nbytes), ipc_error=str(exc))
             if not is_root:
                 return None
-            return np.stack(parts).reshape((shape[1], self.world) + tuple(shape[2:])).swapaxes(0, 1)
+            out = np.empty(shape, dtype=dtype)
+            for g, part in enumerate(parts):
+                out[gdist.owner(g, self.world), g // self.world] = part
+            return out
         t1 = time.perf_counter()
         out = d_recv.download(shape, dtype=dtype, out=self.destination(shape)) if is_root else None
         self.finish_destination()
@@ -417,7 +421,7 @@ class DeviceGather:
         d_rows.free()
         if self.rank != self.root:
             return None
-        return [rows[g % self.world, g // self.world] for g in range(n_points)]
+        return [rows[gdist.owner(g, self.world), g // self.world] for g in range(n_points)]
 
 
 class SharedHostGather:
@@ -433,7 +437,7 @@ class SharedHostGather:
     pack, exchange and download are not three phases but one pipeline per rank, and there is no exchange.
 
     Layout of the segment: [world][slots][samples per point][width] -- rank r's points in its own contiguous block, grid point g
-    at [g mod world, g div world] (the layout `DeviceGather` produces on rank 0).  If the segment cannot be set up (agreed on by
+    at [owner(g), g div world] (the layout `DeviceGather` produces on rank 0).  If the segment cannot be set up (agreed on by
     all ranks inside `HostSegment`), every rank reads back into private memory and the blocks go to rank 0 over the control
     plane (`dist.gather_chains_to_root`); `stats["delivery"]` says which."""
 
@@ -531,7 +535,7 @@ class SharedHostGather:
         self.stats["wait_for_peers_s"] = time.perf_counter() - t1
         if self.rank != self.root:
             return None
-        return [self._all[g % self.world, g // self.world] for g in range(n_points)]
+        return [self._all[gdist.owner(g, self.world), g // self.world] for g in range(n_points)]
 
     def release(self):
         """Drop this object's views of the segment and unmap it (the arrays `run` handed out on rank 0 keep the pages for as long

@@ -165,7 +165,7 @@ class _Job:
 
 @pytest.mark.parametrize("n_points,world,with_rows", [(5, 2, False), (7, 3, True), (4, 3, False), (8, 2, True), (3, 3, False), (9, 4, True)])
 def test_device_gather_packing_and_indexing_with_a_fake_rccl(n_points, world, with_rows, monkeypatch):
-    """Grid point g must come back from slot [g mod world, g div world] whatever the grid / world sizes: grids that do not
+    """Grid point g must come back from slot [owner(g), g div world] whatever the grid / world sizes: grids that do not
     divide evenly, ranks with fewer points than slots.  (A rank with NO point never reaches the gather: scan.main and
     bench.py use the device gather only when there are at least as many grid points as ranks.)"""
     monkeypatch.setenv("GF_SCAN_PREFAULT", "1")

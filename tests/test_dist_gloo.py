@@ -14,6 +14,15 @@ def test_shard_partition_is_exact():
             seen = sorted(g for r in range(world) for g in gdist.shard(n, r, world))
             assert seen == list(range(n))
             assert max([len(gdist.shard(n, r, world)) for r in range(world)] + [0]) == gdist.slots_per_rank(n, world)
+            for r in range(world):
+                pts = gdist.shard(n, r, world)
+                assert all(gdist.owner(g, world) == r for g in pts)
+                assert [g // world for g in pts] == list(range(len(pts)))          # a point's slot on its rank is g div world
+    # the skew spreads what plain g mod world piles up: the C5 grid's fastest axis is the scale (8 values), and on 8 ranks its 32
+    # top-scale points -- the expensive ones -- must not all land on one rank
+    top = [g for g in range(256) if g % 8 == 7]
+    per_rank = [sum(gdist.owner(g, 8) == r for g in top) for r in range(8)]
+    assert per_rank == [4] * 8
     with pytest.raises(ValueError):
         gdist.shard(4, 2, 2)
 
