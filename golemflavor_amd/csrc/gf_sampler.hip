@@ -537,6 +537,11 @@ struct ChainArgs {
     double* lazy_rows;              // [nchains][lazy_cap][GF_PEND_STRIDE]: undecided proposals that are rejected either way ...
     unsigned long long* lazy_mask;  // [nchains][lazy_cap]: ... with their undecided bins (k_stretch_chain settles them in bulk)
     int32_t lazy_cap;
+    // k_stretch_flow: versioned walker states and the in-flight proposals' rows / Hamiltonian terms
+    double* pv;                     // [nchains][FLOW_VERS][nwalkers][ndim]: a walker's position after its v-th update, in slot v mod FLOW_VERS
+    double* lv;                     // [nchains][FLOW_VERS][nwalkers]
+    double* frows;                  // [nchains][nwalkers][GF_PEND_STRIDE]: the parked proposal of a walker (it has at most one in flight)
+    double* fterms;                 // [nchains][nwalkers][9][8]: its two Hamiltonian terms once a team has built them
     unsigned long long* stats;      // [nchains][8] (may be null): per chain, ns on the 100 MHz wall clock spent in [0] proposals, [1] settling
                                     // parked proposals, [2] bulk settlement; [3] proposals waited for, [4] passes that waited, [5] settled in bulk,
                                     // [6] passes, [7] bulk settlements
@@ -864,8 +869,350 @@ __global__ __launch_bounds__(CH_BLOCK) void k_stretch_chain(const ChainArgs s)
     flush_lazy();
 }
 
-hipError_t launch_chain(int ndim, int nchains, const ChainArgs& a, hipStream_t st)
+#ifdef GF_EXPERIMENTAL_FLOW
+// (measured and not kept, round 4 -- compiled only with -DGF_EXPERIMENTAL_FLOW, selected with GF_SAMPLER_CHAIN=3: bitwise the grid
+// sampler's chain on the full C5 scan, 480 rounds for 400 half-steps on the heaviest chain -- the dataflow does what it should -- but
+// a round costs a full proposal phase AND a full settle slice one after the other (55 + 65 us measured, thread 0 building the unit
+// list serially among it), 190 us per half-step against 152 for k_stretch_chain and 117 for the grid kernels; a work-conserving
+// version (any wave proposing or settling as needed) is bounded at ~64 us per half-step for such a chain by the emulated-x87 work
+// itself: profiles/r04/chain_dataflow_not_kept.txt)
+// ---- the same chain as a DATAFLOW inside the workgroup ---------------------------------------------------------------------------
+// k_stretch_chain still moves a chain half-step by half-step: when a half-step parks proposals, ALL its walkers wait until the parked
+// ones are settled -- and the census says that the chains which bound a scan park ~10 proposals in every half-step and spend half
+// their time in that wait (profiles/r04/chain_census.txt).  But a stretch move needs only TWO inputs: the walker's own position and
+// its partner's.  So here every walker carries the count of updates it has completed; a walker's next update runs as soon as its own
+// previous update and its partner's required one are FINAL, whatever the rest of the ensemble is doing; a parked proposal is settled
+// in slices (one team-unit of ~16-23 us per round: the walker's terms, then its undecided bins, highest energy first, stopping at the
+// first failure) while everybody who does not depend on it moves on, and the walkers that fell behind catch up at one update per
+// round.  A walker's last FLOW_VERS positions are kept (slot = update count mod FLOW_VERS) and nobody runs more than FLOW_AHEAD
+// updates ahead of the slowest, so a partner's required version is always still there.  Every update is the computation
+// k_stretch / k_stretch_chain make -- same Philox counter (walker slot, half-step), same inputs, same accept rule, same stored
+// sample -- only the ORDER in which independent updates are executed differs: the chain is the same bit for bit.
+//
+// One round:  P  thread w (= walker w) proposes if its inputs are final: decided -> final at once; undecided and rejected either way ->
+//                final, verdict counted later (bulk); undecided and the verdict decides -> parked (row kept, walker busy)
+//             S  one slice of settling: up to 56 units -- TERMS of a newly parked proposal, or one (walker, bin) PAIR of one whose
+//                terms are ready, handed out rank-major -- one per nine-lane team; proposals whose bins are all done (or one failed)
+//                are completed: accept step, new version, walker free again
+// Barriers only, no wave ever waits for another outside them.
+constexpr int FLOW_VERS = 4;
+constexpr int FLOW_AHEAD = 2;
+constexpr unsigned int FLOW_TERMS = 255u;                 // unit kind: build the Hamiltonian terms (else: the rank of the bin to evaluate)
+// e_info: bits 0-6 undecided bins (<= 64), 7-13 ranks handed out, 14-20 pairs done, 21 one failed, 22 terms being built, 23 terms ready, 24 dead
+#define FLOW_NBITS(i) ((i) & 127u)
+#define FLOW_STARTED(i) (((i) >> 7) & 127u)
+#define FLOW_DONE(i) (((i) >> 14) & 127u)
+#define FLOW_ONE_STARTED (1u << 7)
+#define FLOW_ONE_DONE (1u << 14)
+#define FLOW_FAIL (1u << 21)
+#define FLOW_TBUSY (1u << 22)
+#define FLOW_TREADY (1u << 23)
+#define FLOW_DEAD (1u << 24)
+
+// one walker's update u of k_stretch_flow: returns true when the walker is final again (decided here), false when its proposal was parked
+template <int NDIM>
+__device__ __attribute__((noinline)) bool flow_propose(const ChainArgs& s, const GfCommon& c, const GfBsm* __restrict__ tb, LdsD ctab_l, LdsD ttab_l,
+                                                       LdsD row_l, const int chain, const int w, const unsigned int u, const int wj,
+                                                       const unsigned int need, const double z, const double u3, double* lz_rows,
+                                                       unsigned long long* lz_mask, LdsU new_n, LdsI new_w, LdsL new_mask, LdsU lz_n)
 {
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    const double* ctab = (const double*)ctab_l;
+    const double* ttab = (const double*)ttab_l;
+    double* row = (double*)row_l;
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int nw = s.nwalkers;
+    const int64_t run_step = s.run_step_base + (int64_t)u;
+    const bool store_now = s.store != 0 && s.chain != nullptr && (run_step % s.thin) == 0;
+    const int64_t store_index = s.store_base + (run_step + s.thin - 1) / s.thin;
+    const size_t vbase = (size_t)chain * FLOW_VERS;
+    const double* sk = s.pv + ((vbase + (u & (FLOW_VERS - 1))) * nw + w) * ndim;
+    const double* cj = s.pv + ((vbase + (need & (FLOW_VERS - 1))) * nw + wj) * ndim;
+    double* nx = s.pv + ((vbase + ((u + 1u) & (FLOW_VERS - 1))) * nw + w) * ndim;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (!NDIM && d >= ndim) break;
+        const double cv = cj[d];
+        row[d] = fma(-z, cv - sk[d], cv);
+    }
+    int st;
+    unsigned long long pending;
+    const double lnq = proposal_lnprob<NDIM, MODE_BSM_GAUSS, 1>(c, tb, ctab, ttab, row, ndim, st, 0, nullptr, pending);
+    const double lnk = s.lv[(vbase + (u & (FLOW_VERS - 1))) * nw + w];
+    double zp = 1.0;
+    for (int d = 1; d < ndim; ++d) zp *= z;
+    const double lhs = log(zp / u3);
+    bool accept = lhs > lnk - lnq;                        // false for NaN and for lnq = -inf
+    if (pending != 0ull && accept) {
+        double* dst = s.frows + ((size_t)chain * nw + w) * GF_PEND_STRIDE;
+        for (int d = 0; d < ndim; ++d) dst[d] = row[d];
+        dst[GF_MAX_DIM] = lnq;
+        const unsigned int at = atomicAdd((unsigned int*)new_n, 1u);
+        new_w[at] = w;
+        new_mask[at] = pending;
+        return false;
+    }
+    if (pending != 0ull) {                                // undecided, rejected either way: only the count wants the verdict
+        const unsigned int at = atomicAdd((unsigned int*)lz_n, 1u);
+        double* dst = lz_rows + (size_t)at * GF_PEND_STRIDE;
+        for (int d = 0; d < ndim; ++d) dst[d] = row[d];
+        lz_mask[at] = pending;
+    }
+    if (st == ST_NON_UNITARY) { accept = false; atomicAdd(s.flags, 1u); }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (!NDIM && d >= ndim) break;
+        nx[d] = accept ? row[d] : sk[d];
+    }
+    s.lv[(vbase + ((u + 1u) & (FLOW_VERS - 1))) * nw + w] = accept ? lnq : lnk;
+    if (accept) s.naccept[(int64_t)chain * nw + w] += 1u;
+    if (store_now) {
+        double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * nw + w) * ndim;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (!NDIM && d >= ndim) break;
+            dst[d] = accept ? row[d] : sk[d];
+        }
+        if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = accept ? lnq : lnk;
+    }
+    return true;
+}
+
+template <int NDIM>
+__global__ __launch_bounds__(CH_BLOCK) void k_stretch_flow(const ChainArgs s)
+{
+    constexpr int ND = NDIM ? NDIM : GF_MAX_DIM;
+    constexpr int TEAMS = CH_WAVES * Team9::PER_WAVE;
+    constexpr int TEAM_DOUBLES = TEAMS * Team9::DOUBLES;
+    constexpr int TILE_DOUBLES = CH_WAVES * GF_WAVE * ND;
+    __shared__ __attribute__((aligned(16))) double uni[TEAM_DOUBLES > TILE_DOUBLES ? TEAM_DOUBLES : TILE_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double ctab[GF_MAX_DIM * 4 + 20];
+    __shared__ __attribute__((aligned(16))) double wt[WT_DOUBLES];      // chain_settle (the bulk settlement of the count-only proposals)
+    __shared__ unsigned int du[CH_BLOCK];                 // updates completed, per walker
+    __shared__ unsigned int busy[CH_BLOCK];               // the walker has a parked proposal in flight
+    __shared__ int e_w[CH_BLOCK];                         // parked proposals in flight: walker ...
+    __shared__ unsigned long long e_mask[CH_BLOCK];       // ... undecided bins ...
+    __shared__ unsigned int e_info[CH_BLOCK];             // ... progress (FLOW_* above)
+    __shared__ int new_w[CH_BLOCK];
+    __shared__ unsigned long long new_mask[CH_BLOCK];
+    __shared__ unsigned int unit_e[TEAMS], unit_r[TEAMS];
+    __shared__ unsigned int pk_ctl[2 * CH_BLOCK];         // chain_settle's counters (zero between uses)
+    __shared__ unsigned int e_n, new_n, unit_n, lz_n, min_u, pk_head, pk_aux;
+
+    const int chain = blockIdx.x;
+    const GfCommon& c = s.commons[s.nmodels > 1 ? chain : 0];
+    const GfBsm* __restrict__ tb = s.nmodels > 1 ? s.tbs[chain] : s.tb;
+    const double* __restrict__ ptab = s.ptabs[s.nmodels > 1 ? chain : 0];
+    double* ttab = ctab + GF_MAX_DIM * 4;
+    if (threadIdx.x < GF_MAX_DIM * 4) ctab[threadIdx.x] = ptab[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 18) {
+        const int k = threadIdx.x - 64, e = k >> 1;
+        const int idx = e == 0 ? 0 : e == 1 ? 4 : e == 2 ? 8 : e <= 4 ? 1 : e <= 6 ? 2 : 5;
+        const bool im = e == 4 || e == 6 || e == 8;
+        const double* srcp = (k & 1) ? (im ? tb->t2_im : tb->t2_re) : (im ? tb->t1_im : tb->t1_re);
+        ttab[k] = srcp[idx];
+    }
+    const int ndim = NDIM ? NDIM : c.ndim;
+    const int nw = s.nwalkers, nhalf = nw / 2;
+    const unsigned int U_END = (unsigned int)s.nsteps;
+    const int tid = threadIdx.x, lane = tid & (GF_WAVE - 1), wave = tid / GF_WAVE;
+    const size_t vbase = (size_t)chain * FLOW_VERS;
+    // version 0 = the state the launch starts from
+    for (int i = tid; i < nw * ndim; i += CH_BLOCK) s.pv[vbase * nw * ndim + i] = s.pos[(size_t)chain * nw * ndim + i];
+    for (int i = tid; i < nw; i += CH_BLOCK) s.lv[vbase * nw + i] = s.lnp[(size_t)chain * nw + i];
+    du[tid] = tid < nw ? 0u : U_END;
+    busy[tid] = 0u;
+    pk_ctl[tid] = 0u; pk_ctl[CH_BLOCK + tid] = 0u;
+    if (tid == 0) { e_n = 0u; lz_n = 0u; }
+    __syncthreads();
+
+    const uint64_t sid = s.stream_ids ? s.stream_ids[chain] : (uint64_t)chain;
+    const uint32_t k0s = (uint32_t)s.seed, k1s = (uint32_t)(s.seed >> 32);
+    double* row = uni + (size_t)wave * GF_WAVE * ND + (size_t)lane * ndim;
+    double* const lz_rows = s.lazy_rows + (size_t)chain * s.lazy_cap * GF_PEND_STRIDE;
+    unsigned long long* const lz_mask = s.lazy_mask + (size_t)chain * s.lazy_cap;
+    unsigned long long* const stat = s.stats ? s.stats + (size_t)chain * 8 : nullptr;
+    const int grp = lane / Team9::LANES;
+    const bool team_active = grp < Team9::PER_WAVE;
+    const int tl = lane - grp * Team9::LANES;
+    const int team = wave * Team9::PER_WAVE + grp;
+    auto flush_lazy = [&]() {                              // workgroup-uniform call; barriers inside
+        const unsigned int n = lz_n;
+        if (n != 0u) {
+            const unsigned long long t0 = wall_clock64();
+            chain_settle(uni, wt, n, &pk_head, &pk_aux, pk_ctl, c, tb,
+                         [&](unsigned int i) { return lz_rows + (size_t)i * GF_PEND_STRIDE; },
+                         [&](unsigned int i) { return lz_mask[i]; },
+                         [&](unsigned int, bool bad) { if (bad) atomicAdd(s.flags, 1u); });
+            __syncthreads();
+            if (tid == 0) {
+                lz_n = 0u;
+                if (stat) { stat[2] += 10ull * (wall_clock64() - t0); stat[5] += n; stat[7] += 1ull; }
+            }
+            __syncthreads();
+        }
+    };
+
+    const unsigned int round_limit = 64u * U_END + 4096u;  // a chain needs 2 U_END rounds when nothing is parked: far below this
+    for (unsigned int round = 0;; ++round) {
+        if (tid == 0) { min_u = U_END; new_n = 0u; }
+        __syncthreads();
+        if (tid < nw) atomicMin(&min_u, du[tid]);
+        __syncthreads();
+        const unsigned int mu = min_u;
+        if (mu >= U_END && e_n == 0u) break;               // every walker has made its updates and nothing is in flight
+        if (round > round_limit) { if (tid == 0) atomicAdd(s.flags + 1, 1u); break; }    // (never: reported by the host)
+        if (lz_n + (unsigned int)nw > (unsigned int)s.lazy_cap) flush_lazy();
+        const unsigned long long t_p = wall_clock64();
+        // ---- P: every walker whose inputs are final makes its next update
+        bool fin = false;
+        unsigned int u = 0u;
+        if (tid < nw && busy[tid] == 0u) {
+            u = du[tid];
+            if (u < U_END && u <= mu + (unsigned int)FLOW_AHEAD) {
+                const int half = tid >= nhalf ? 1 : 0;
+                const int k = tid - half * nhalf;
+                const uint64_t g = sid * (uint64_t)nhalf + (uint64_t)k;
+                const uint64_t ctr = 2 * (s.iteration_base + (uint64_t)u) + (uint64_t)half;
+                uint32_t r[4];
+                philox_block((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), k0s, k1s, r);
+                const int j = (int)(((uint64_t)r[2] * (uint64_t)nhalf) >> 32);
+                const int wj = (1 - half) * nhalf + j;
+                const unsigned int need = u + (unsigned int)half;     // updates the partner must have completed: its position BEFORE this half-step
+                if (du[wj] >= need) {
+                    const double u1 = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+                    const double u3 = ((double)r[3] + 0.5) * (1.0 / 4294967296.0);
+                    const double zr = fma(s.a - 1.0, u1, 1.0);
+                    const double z = zr * zr / s.a;
+                    fin = flow_propose<NDIM>(s, c, tb, (LdsD)ctab, (LdsD)ttab, (LdsD)row, chain, tid, u, wj, need, z, u3, lz_rows, lz_mask,
+                                             (LdsU)&new_n, (LdsI)new_w, (LdsL)new_mask, (LdsU)&lz_n);
+                    if (!fin) busy[tid] = 1u;
+                }
+            }
+        }
+        __syncthreads();                                    // every read of du[] of this round is done
+        if (fin) du[tid] = u + 1u;
+        // the newly parked proposals join the list
+        const unsigned int nn = new_n, base = e_n;
+        if ((unsigned int)tid < nn) {
+            e_w[base + tid] = new_w[tid];
+            e_mask[base + tid] = new_mask[tid];
+            e_info[base + tid] = (unsigned int)__popcll(new_mask[tid]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            e_n = base + nn;
+            if (stat) { stat[0] += 10ull * (wall_clock64() - t_p); stat[6] += 1ull; stat[3] += nn; }
+        }
+        __syncthreads();
+        const unsigned int ne = e_n;
+        if (ne == 0u) continue;
+        // ---- S: one slice.  Thread 0 hands out the units: the terms of every proposal that has none yet, then pairs rank-major
+        const unsigned long long t_s = wall_clock64();
+        if (tid == 0) {
+            unsigned int n = 0;
+            for (unsigned int e = 0; e < ne && n < (unsigned int)TEAMS; ++e)
+                if ((e_info[e] & (FLOW_TBUSY | FLOW_TREADY)) == 0u) { unit_e[n] = e; unit_r[n] = FLOW_TERMS; ++n; e_info[e] |= FLOW_TBUSY; }
+            bool more = true;
+            while (more && n < (unsigned int)TEAMS) {
+                more = false;
+                for (unsigned int e = 0; e < ne && n < (unsigned int)TEAMS; ++e) {
+                    const unsigned int inf = e_info[e];
+                    if ((inf & FLOW_TREADY) && !(inf & FLOW_FAIL) && FLOW_STARTED(inf) < FLOW_NBITS(inf)) {
+                        unit_e[n] = e; unit_r[n] = FLOW_STARTED(inf); ++n;
+                        e_info[e] = inf + FLOW_ONE_STARTED;
+                        more = true;
+                    }
+                }
+            }
+            unit_n = n;
+        }
+        __syncthreads();
+        if (team_active && (unsigned int)team < unit_n) {
+            Team9 tm;
+            tm.init(uni + (size_t)team * Team9::DOUBLES, tl);
+            const unsigned int e = unit_e[team], r = unit_r[team];
+            const int w = e_w[e];
+            double* ft = s.fterms + (((size_t)chain * nw + w) * Team9::LANES + tl) * 8;
+            if (r == FLOW_TERMS) {
+                tm.terms(c, *tb, s.frows + ((size_t)chain * nw + w) * GF_PEND_STRIDE, 0, 1, 0, GF_PEND_STRIDE);
+                ft[0] = tm.hs.re.hi; ft[1] = tm.hs.re.lo; ft[2] = tm.hs.im.hi; ft[3] = tm.hs.im.lo;
+                ft[4] = tm.hn.re.hi; ft[5] = tm.hn.re.lo; ft[6] = tm.hn.im.hi; ft[7] = tm.hn.im.lo;
+                if (tm.leader()) atomicOr(&e_info[e], FLOW_TREADY);
+            } else {
+                tm.hs.re.hi = ft[0]; tm.hs.re.lo = ft[1]; tm.hs.im.hi = ft[2]; tm.hs.im.lo = ft[3];
+                tm.hn.re.hi = ft[4]; tm.hn.re.lo = ft[5]; tm.hn.im.hi = ft[6]; tm.hn.im.lo = ft[7];
+                const int kk = nth_bit_from_top(e_mask[e], r);
+                const double res = tm.bin(tb->inv2e[kk], tb->epow[kk]);
+                if (tm.leader()) {
+                    if (!(res < 1e-7)) atomicOr(&e_info[e], FLOW_FAIL);          // fr.py:493-494 (NaN raises too)
+                    atomicAdd(&e_info[e], FLOW_ONE_DONE);
+                }
+            }
+        }
+        __syncthreads();
+        // complete what is settled: every bin done, or one failed (its started pairs have all ended with this slice)
+        if ((unsigned int)tid < ne) {
+            const unsigned int inf = e_info[tid];
+            const bool failed = (inf & FLOW_FAIL) != 0u;
+            if ((inf & FLOW_TREADY) && (failed || FLOW_DONE(inf) == FLOW_NBITS(inf)) && FLOW_DONE(inf) == FLOW_STARTED(inf)) {
+                const int w = e_w[tid];
+                const unsigned int uw = du[w];
+                const double* prow = s.frows + ((size_t)chain * nw + w) * GF_PEND_STRIDE;
+                const double* old = s.pv + ((vbase + (uw & (FLOW_VERS - 1))) * nw + w) * ndim;
+                double* nx = s.pv + ((vbase + ((uw + 1u) & (FLOW_VERS - 1))) * nw + w) * ndim;
+                const double lnq = prow[GF_MAX_DIM];
+                const double lnk = s.lv[(vbase + (uw & (FLOW_VERS - 1))) * nw + w];
+                const bool accept = !failed;                 // the accept test itself passed when the proposal was parked
+                if (failed) atomicAdd(s.flags, 1u);
+                for (int d = 0; d < ndim; ++d) nx[d] = accept ? prow[d] : old[d];
+                s.lv[(vbase + ((uw + 1u) & (FLOW_VERS - 1))) * nw + w] = accept ? lnq : lnk;
+                if (accept) s.naccept[(int64_t)chain * nw + w] += 1u;
+                const int64_t run_step = s.run_step_base + (int64_t)uw;
+                if (s.store != 0 && s.chain != nullptr && (run_step % s.thin) == 0) {
+                    const int64_t store_index = s.store_base + (run_step + s.thin - 1) / s.thin;
+                    double* dst = s.chain + (((int64_t)chain * s.nstore_cap + store_index) * nw + w) * ndim;
+                    for (int d = 0; d < ndim; ++d) dst[d] = accept ? prow[d] : old[d];
+                    if (s.lnp_chain) s.lnp_chain[((int64_t)chain * s.nstore_cap + store_index) * nw + w] = accept ? lnq : lnk;
+                }
+                du[w] = uw + 1u;
+                busy[w] = 0u;
+                e_info[tid] = inf | FLOW_DEAD;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                                     // close the gaps
+            unsigned int m = 0;
+            for (unsigned int e = 0; e < ne; ++e)
+                if (!(e_info[e] & FLOW_DEAD)) { if (m != e) { e_w[m] = e_w[e]; e_mask[m] = e_mask[e]; e_info[m] = e_info[e]; } ++m; }
+            e_n = m;
+            if (stat) { stat[1] += 10ull * (wall_clock64() - t_s); stat[4] += 1ull; }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    flush_lazy();
+    // the state the launch ends with
+    for (int i = tid; i < nw * ndim; i += CH_BLOCK) s.pos[(size_t)chain * nw * ndim + i] = s.pv[(vbase + (U_END & (FLOW_VERS - 1))) * nw * ndim + i];
+    for (int i = tid; i < nw; i += CH_BLOCK) s.lnp[(size_t)chain * nw + i] = s.lv[(vbase + (U_END & (FLOW_VERS - 1))) * nw + i];
+}
+
+#endif  // GF_EXPERIMENTAL_FLOW
+
+hipError_t launch_chain(int ndim, int nchains, const ChainArgs& a, hipStream_t st, bool flow)
+{
+#ifdef GF_EXPERIMENTAL_FLOW
+    if (flow) {
+        switch (ndim) {
+        case 7: hipLaunchKernelGGL(k_stretch_flow<7>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+        case 12: hipLaunchKernelGGL(k_stretch_flow<12>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+        default: hipLaunchKernelGGL(k_stretch_flow<0>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
+        }
+        return hipGetLastError();
+    }
+#else
+    (void)flow;
+#endif
     switch (ndim) {
     case 7: hipLaunchKernelGGL(k_stretch_chain<7>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
     case 12: hipLaunchKernelGGL(k_stretch_chain<12>, dim3(nchains), dim3(CH_BLOCK), 0, st, a); break;
@@ -951,6 +1298,10 @@ struct gf_sampler {
     unsigned long long* d_lazy_mask = nullptr;   // [nchains][lazy_cap]
     int lazy_cap = 0;
     unsigned long long* d_chain_stats = nullptr;   // [nchains][8]: k_stretch_chain's per-chain census (ChainArgs::stats), zeroed by gf_sampler_reset
+    double* d_pv = nullptr;                        // k_stretch_flow: [nchains][FLOW_VERS][nwalkers][ndim] versioned positions ...
+    double* d_lv = nullptr;                        // ... [nchains][FLOW_VERS][nwalkers] lnprob
+    double* d_frows = nullptr;                     // ... [nchains][nwalkers][GF_PEND_STRIDE] parked proposals
+    double* d_fterms = nullptr;                    // ... [nchains][nwalkers][72] their Hamiltonian terms
     // launch shape of a BSM sampler on small ensembles: 0 = not decided yet, 1 = one workgroup per chain (k_stretch_chain), 2 = the
     // per-half-step grid kernels + k_stretch_settle.  Decided at the start of every run of 128 steps or more, by timing a block of 16
     // steps of each on the sampler's own chains (gf_sampler_run); GF_SAMPLER_CHAIN=0 / 1 forces one
@@ -1097,6 +1448,10 @@ void gf_sampler_destroy(gf_sampler* s)
     if (s->d_lazy_rows) (void)hipFree(s->d_lazy_rows);
     if (s->d_lazy_mask) (void)hipFree(s->d_lazy_mask);
     if (s->d_chain_stats) (void)hipFree(s->d_chain_stats);
+    if (s->d_pv) (void)hipFree(s->d_pv);
+    if (s->d_lv) (void)hipFree(s->d_lv);
+    if (s->d_frows) (void)hipFree(s->d_frows);
+    if (s->d_fterms) (void)hipFree(s->d_fterms);
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     for (int i = 0; i < gf_sampler::FLIGHT; ++i) if (s->flight_ev[i]) (void)hipEventDestroy(s->flight_ev[i]);
@@ -1426,13 +1781,14 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
     const bool small_bsm = c->mode == MODE_BSM_GAUSS && s->nwalkers / 2 <= 512;
     constexpr int64_t CHAIN_STEPS = 16;                                  // steps per launch: the granule of the overlapped read-back
     ChainArgs ca = {};
+    bool flow = false;                                                   // per chain as a dataflow (k_stretch_flow) or half-step by half-step (k_stretch_chain)
     auto chain_block = [&](int64_t count) -> int {                       // `count` steps from `done` on, one launch
         hipError_t e = flight_admit(s);
         if (e != hipSuccess) return sfail(e, "block in flight");
         ca.iteration_base = s->iteration + (uint64_t)done;
         ca.run_step_base = done;
         ca.nsteps = (int32_t)count;
-        e = launch_chain(s->ndim, s->nchains, ca, st);
+        e = launch_chain(s->ndim, s->nchains, ca, st, flow);
         if (e != hipSuccess) return sfail(e, "chain launch");
         done += count;
         e = flight_mark(s, st, store ? s->nstored + (done + thin - 1) / thin : s->nstored);
@@ -1450,13 +1806,16 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         return GF_OK;
     };
     if (small_bsm) {
-        const char* env = gf_internal_env("GF_SAMPLER_CHAIN", 0);
-        const bool forced = env && (env[0] == '0' || env[0] == '1');
+        const char* env = gf_internal_env("GF_SAMPLER_CHAIN", 0);       // "0": grid kernels; "1": per chain (k_stretch_chain)
+        const bool forced = env && (env[0] == '0' || env[0] == '1' || env[0] == '3');
         int shape = forced ? (env[0] == '0' ? 2 : 1) : (nsteps >= 8 * CHAIN_STEPS ? 0 : s->shape);
+#ifdef GF_EXPERIMENTAL_FLOW
+        flow = s->nwalkers <= CH_BLOCK && env && env[0] == '3';               // the dataflow kernel has one thread per walker
+#endif
         if (shape != 2) {
             if (!s->d_lazy_rows) {
                 // room for the proposals whose verdict only the count waits for: at least two passes' worth per chain, ~64 MB in all
-                const int pass = s->nwalkers / 2 < CH_BLOCK ? s->nwalkers / 2 : CH_BLOCK;
+                const int pass = s->nwalkers < CH_BLOCK ? s->nwalkers : CH_BLOCK;          // (k_stretch_flow: up to nwalkers per round)
                 int64_t cap = ((int64_t)64 << 20) / ((int64_t)s->nchains * (int64_t)(sizeof(double) * GF_PEND_STRIDE + 8));
                 if (cap > 1024) cap = 1024;
                 if (cap < 2 * pass) cap = 2 * pass;
@@ -1478,6 +1837,17 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             ca.chain = store ? s->d_chain : nullptr; ca.lnp_chain = store ? s->d_lnp_chain : nullptr;
             ca.nstore_cap = s->nstore_cap; ca.store_base = s->nstored; ca.seed = s->seed; ca.thin = thin; ca.store = store ? 1 : 0;
             ca.a = s->a; ca.stream_ids = s->d_stream_ids;
+#ifdef GF_EXPERIMENTAL_FLOW
+            if (flow && !s->d_pv) {
+                const size_t nwk = (size_t)s->nchains * s->nwalkers;
+                hipError_t e_ = hipMalloc((void**)&s->d_pv, sizeof(double) * FLOW_VERS * nwk * s->ndim);
+                if (e_ == hipSuccess) e_ = hipMalloc((void**)&s->d_lv, sizeof(double) * FLOW_VERS * nwk);
+                if (e_ == hipSuccess) e_ = hipMalloc((void**)&s->d_frows, sizeof(double) * GF_PEND_STRIDE * nwk);
+                if (e_ == hipSuccess) e_ = hipMalloc((void**)&s->d_fterms, sizeof(double) * Team9::LANES * 8 * nwk);
+                if (e_ != hipSuccess) return sfail(e_, "hipMalloc(dataflow sampler)");
+            }
+            ca.pv = s->d_pv; ca.lv = s->d_lv; ca.frows = s->d_frows; ca.fterms = s->d_fterms;
+#endif
         }
         if (shape == 0 && !forced && nsteps >= 8 * CHAIN_STEPS) {
             // the probe: two blocks per chain, two blocks on the grid, the second of each timed

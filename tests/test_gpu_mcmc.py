@@ -346,15 +346,17 @@ def test_scan_rows_to_host_equal_rows_on_device():
 
 def test_grid_point_chain_does_not_depend_on_the_sharding():
     """Every chain of a stacked scan draws from the random stream of its GLOBAL grid index (gf_sampler_set_stream_ids):
-    grid points 1 and 3 give bitwise the same chains whether their rank holds all four points (world 1) or just
-    those two (rank 1 of world 2), and so does the one-sampler-per-point path's keying by grid index."""
+    rank 1's two grid points of world 2 (`dist.shard`: points 1 and 2 under the skewed round robin) give bitwise the same chains
+    whether their rank holds all four points (world 1) or just those two, and so does the one-sampler-per-point path's keying by
+    grid index."""
     from golemflavor_amd import scan
     pts = scan.sens_grid(n_scales=2, n_sources=1)[:4]
     make = lambda p, g: scan._SensPoint(p, g, nwalkers=32, device=0)   # noqa: E731
     full = scan.run_points(pts, [0, 1, 2, 3], make, 5, 12)
-    half = scan.run_points(pts, gdist.shard(4, 1, 2), make, 5, 12)
-    assert sorted(half) == [1, 3]
-    for g in (1, 3):
+    mine = gdist.shard(4, 1, 2)
+    half = scan.run_points(pts, mine, make, 5, 12)
+    assert sorted(half) == mine == [1, 2]
+    for g in mine:
         assert np.array_equal(full[g], half[g])
     assert not np.array_equal(full[0][:, :4], full[1][:, :4])          # distinct streams per grid point
 

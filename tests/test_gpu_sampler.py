@@ -207,7 +207,7 @@ def test_per_chain_sampler_equals_grid_sampler(monkeypatch, nwalkers, stacked):
     p0 = rng.uniform(box[:, 0], box[:, 1], size=(nch, nwalkers, 12))
     p0[:, :, 11] = rng.uniform(-40.0, -30.0, (nch, nwalkers))            # across the top of the scale range: the assert fires there
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0"):                                               # one workgroup per chain / per-half-step grid kernels
         monkeypatch.setenv("GF_SAMPLER_CHAIN", mode)
         s = mcmc_utils.DeviceEnsembleSampler(nwalkers, 12, post, nchains=nch, seed=5, stream_ids=[7, 2, 40])
         s.on_nonunitary = "-inf"
