@@ -1315,6 +1315,101 @@ int gf_internal_d2h_2d(int device, void* stream, void* dst_host, size_t dpitch, 
     return GF_OK;
 }
 
+// ---- one read-back pipeline over MANY pitched blocks (gf_sampler_run_to_host) ---------------------------------------------------------
+// gf_internal_d2h_2d is a pipeline per call: thread start, ring fill and ring drain every time.  A chain that leaves the device block of
+// steps by block of steps while it is sampled (62 blocks of 201 MB for the C5 scan at the reference's length) paid that 62 times and
+// reached 31 GB/s where the link gives 48 (profiles/r04/readback_overlap.txt).  A pipe keeps ONE consumer thread and the ring's state
+// across blocks: gf_internal_d2h_pipe_rows returns as soon as the block's chunks have been ISSUED (the DMA of chunk c runs while the host
+// threads empty chunk c - 1 into the destination), the next block's chunks follow without a gap, and only _close drains.
+struct gf_d2h_pipe {
+    int device = 0;
+    hipStream_t st = nullptr;
+    D2HRing* ring = nullptr;
+    struct Chunk { char* dst; size_t dpitch, width, nrows; } desc[D2H_SLOTS] = {};
+    std::atomic<size_t> issued{0}, drained{0};
+    std::atomic<int> failed{0}, closing{0};
+    std::thread consumer;
+};
+
+int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !out) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    gf_d2h_pipe* p = new (std::nothrow) gf_d2h_pipe();
+    if (!p) return GF_ERR_ALLOC;
+    p->device = device; p->st = (hipStream_t)stream; p->ring = &g_d2h[device];
+    p->ring->mu.lock();                                   // one large read-back at a time per device; released by _close
+    for (int k = 0; k < D2H_SLOTS; ++k) {
+        hipError_t e = hipSuccess;
+        if (!p->ring->slot[k]) e = hipHostMalloc(&p->ring->slot[k], D2H_SLOT, hipHostMallocDefault);
+        if (e == hipSuccess && !p->ring->ev[k]) e = hipEventCreateWithFlags(&p->ring->ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) { p->ring->mu.unlock(); delete p; return hip_fail(e, "gf_internal_d2h_pipe_open"); }
+    }
+    p->consumer = std::thread([p]() {
+        for (size_t c = 0;; ++c) {
+            while (p->issued.load(std::memory_order_acquire) <= c) {
+                if (p->failed.load() || p->closing.load()) {
+                    if (p->issued.load(std::memory_order_acquire) <= c) return;       // closing and nothing more to empty
+                    break;
+                }
+                std::this_thread::yield();
+            }
+            if (p->failed.load()) return;
+            const int k = (int)(c % D2H_SLOTS);
+            if (hipEventSynchronize(p->ring->ev[k]) != hipSuccess) { p->failed.store(1); return; }
+            const gf_d2h_pipe::Chunk& d = p->desc[k];
+            copy_rows(d.dst, d.dpitch, static_cast<const char*>(p->ring->slot[k]), d.width, d.nrows);
+            p->drained.store(c + 1, std::memory_order_release);
+        }
+    });
+    *out = p;
+    return GF_OK;
+}
+
+// `height` rows of `width` bytes, `spitch` apart on the device, to rows `dpitch` apart on the host; returns once every chunk is issued
+int gf_internal_d2h_pipe_rows(gf_d2h_pipe* p, void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height)
+{
+    if (!p || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
+    if (width == 0 || height == 0) return GF_OK;
+    char* dst = static_cast<char*>(dst_host);
+    const char* src = static_cast<const char*>(src_dev);
+    hipError_t e = hipSuccess;
+    auto issue = [&](char* d, size_t dp, const char* sp, size_t spi, size_t w, size_t nr) {
+        const size_t c = p->issued.load(std::memory_order_relaxed);
+        while (c >= p->drained.load(std::memory_order_acquire) + D2H_SLOTS && !p->failed.load()) std::this_thread::yield();   // the slot is free
+        if (p->failed.load()) return;
+        const int k = (int)(c % D2H_SLOTS);
+        p->desc[k] = {d, dp, w, nr};
+        e = nr == 1 ? hipMemcpyAsync(p->ring->slot[k], sp, w, hipMemcpyDeviceToHost, p->st)
+                    : hipMemcpy2DAsync(p->ring->slot[k], w, sp, spi, w, nr, hipMemcpyDeviceToHost, p->st);
+        if (e == hipSuccess) e = hipEventRecord(p->ring->ev[k], p->st);
+        if (e == hipSuccess) p->issued.store(c + 1, std::memory_order_release);
+    };
+    if (width > D2H_SLOT) {                                 // a row wider than a slot: in pieces
+        for (size_t r = 0; r < height && e == hipSuccess && !p->failed.load(); ++r)
+            for (size_t off = 0; off < width && e == hipSuccess && !p->failed.load(); off += D2H_SLOT)
+                issue(dst + r * dpitch + off, 0, src + r * spitch + off, 0, width - off < D2H_SLOT ? width - off : D2H_SLOT, 1);
+    } else {
+        const size_t rps = D2H_SLOT / width;                // whole rows per slot
+        for (size_t r0 = 0; r0 < height && e == hipSuccess && !p->failed.load(); r0 += rps)
+            issue(dst + r0 * dpitch, dpitch, src + r0 * spitch, spitch, width, height - r0 < rps ? height - r0 : rps);
+    }
+    if (e != hipSuccess) { p->failed.store(1); return hip_fail(e, "gf_internal_d2h_pipe_rows"); }
+    return p->failed.load() ? GF_ERR_HIP : GF_OK;
+}
+
+int gf_internal_d2h_pipe_close(gf_d2h_pipe* p)
+{
+    if (!p) return GF_OK;
+    p->closing.store(1);
+    if (p->consumer.joinable()) p->consumer.join();
+    const int bad = p->failed.load();
+    p->ring->mu.unlock();
+    delete p;
+    if (bad) { std::snprintf(g_err, sizeof(g_err), "gf_internal_d2h_pipe: a copy or an event wait failed"); return GF_ERR_HIP; }
+    return GF_OK;
+}
+
 // diagnostics (tools/readback_ab.py, not part of the ABI): what the link delivers in this process -- `bytes` of device memory copied into
 // PINNED host memory in 64 MiB pieces, no host copy behind them; GB/s
 int gf_internal_pinned_d2h_rate(int device, size_t bytes, double* gbps)

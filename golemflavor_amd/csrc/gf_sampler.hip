@@ -1334,7 +1334,8 @@ struct gf_sampler {
 struct HostSink {
     double* chain; double* lnp; int64_t total;     // host arrays of `total` stored steps per chain
     void* copy_stream; int device;
-    int64_t copied = 0;                            // stored steps already on the host
+    struct gf_d2h_pipe* pipe = nullptr;            // ONE read-back pipeline for the whole run (gf_capi.hip)
+    int64_t copied = 0;                            // stored steps whose copy has been issued
     int rc = GF_OK;
     std::chrono::steady_clock::time_point last_event;   // when the newest consumed block was seen complete
 };
@@ -1358,6 +1359,10 @@ int gf_internal_d2h_gated(int device, void* stream, void* dst_host, const void* 
                           int (*gate)(void* ctx, size_t upto), void* gate_ctx);
 int gf_internal_d2h_2d(int device, void* stream, void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width,
                        size_t height);
+struct gf_d2h_pipe;
+int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out);
+int gf_internal_d2h_pipe_rows(gf_d2h_pipe* p, void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height);
+int gf_internal_d2h_pipe_close(gf_d2h_pipe* p);
 }
 
 namespace {
@@ -1584,7 +1589,8 @@ int gf_sampler_reset(gf_sampler* s)
 }
 
 namespace {
-// the stored steps [sink->copied, upto) of every chain -> host, through the pinned ring, on the sink's stream (synchronous)
+// the stored steps [sink->copied, upto) of every chain -> host: their chunks are ISSUED into the sink's pipe (pinned ring, copy stream); the
+// host threads empty them into the destination while the caller goes on
 int sink_copy(gf_sampler* s, int64_t upto)
 {
     HostSink* k = s->sink;
@@ -1592,13 +1598,24 @@ int sink_copy(gf_sampler* s, int64_t upto)
     if (upto > k->total) upto = k->total;
     const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
     const size_t prev = (size_t)k->copied, now = (size_t)(upto - k->copied);
-    int rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->chain) + row * prev, row * (size_t)k->total,
+    int rc;
+    if (k->pipe) {
+        rc = gf_internal_d2h_pipe_rows(k->pipe, reinterpret_cast<char*>(k->chain) + row * prev, row * (size_t)k->total,
+                                       reinterpret_cast<const char*>(s->d_chain) + row * prev, row * (size_t)s->nstore_cap, row * now,
+                                       (size_t)s->nchains);
+        if (rc == GF_OK && k->lnp)
+            rc = gf_internal_d2h_pipe_rows(k->pipe, reinterpret_cast<char*>(k->lnp) + lrow * prev, lrow * (size_t)k->total,
+                                           reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * prev, lrow * (size_t)s->nstore_cap, lrow * now,
+                                           (size_t)s->nchains);
+    } else {                                               // GF_RUN_TO_HOST_NO_PIPE (A/B): a pipeline of its own per block, as before the pipe
+        rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->chain) + row * prev, row * (size_t)k->total,
                                 reinterpret_cast<const char*>(s->d_chain) + row * prev, row * (size_t)s->nstore_cap, row * now,
                                 (size_t)s->nchains);
-    if (rc == GF_OK && k->lnp)
-        rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->lnp) + lrow * prev, lrow * (size_t)k->total,
-                                reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * prev, lrow * (size_t)s->nstore_cap, lrow * now,
-                                (size_t)s->nchains);
+        if (rc == GF_OK && k->lnp)
+            rc = gf_internal_d2h_2d(k->device, k->copy_stream, reinterpret_cast<char*>(k->lnp) + lrow * prev, lrow * (size_t)k->total,
+                                    reinterpret_cast<const char*>(s->d_lnp_chain) + lrow * prev, lrow * (size_t)s->nstore_cap, lrow * now,
+                                    (size_t)s->nchains);
+    }
     k->rc = rc;
     k->copied = upto;
     return rc;
@@ -1962,6 +1979,10 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     sink.chain = chain; sink.lnp = lnprob_chain; sink.total = s->nstored + (nsteps + thin - 1) / thin;
     sink.copy_stream = copy_stream; sink.device = device;
     sink.last_event = std::chrono::steady_clock::now();
+    if (gf_internal_env("GF_RUN_TO_HOST_NO_PIPE", 0) == nullptr) {       // diagnostics / A-B: else every block is a read-back of its own
+        rc = gf_internal_d2h_pipe_open(device, copy_stream, &sink.pipe);
+        if (rc != GF_OK) { gf_internal_return_stream(device, copy_stream); return rc; }
+    }
     const bool marks = gf_internal_env("GF_RUN_TO_HOST_NO_MARKS", 0) == nullptr;      // diagnostics: no sink during the run = one copy after it
     s->sink = marks ? &sink : nullptr;
     rc = gf_sampler_run(s, nsteps, thin, 1);
@@ -1975,8 +1996,10 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
         (void)sink_copy(s, s->nstored);
         s->sink = nullptr;
     }
+    const int rc_pipe = gf_internal_d2h_pipe_close(sink.pipe);          // drains: every chunk is in the destination
     (void)hipStreamSynchronize((hipStream_t)copy_stream);
     gf_internal_return_stream(device, copy_stream);
+    if (rc == GF_OK && sink.rc == GF_OK) sink.rc = rc_pipe;
     if (readback_tail_s) *readback_tail_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_done).count();
     if (rc != GF_OK) return rc;
     if (sink.rc != GF_OK) return sink.rc;
