@@ -64,3 +64,40 @@ def test_bench_line_sub_records_at_reduced_scan_length():
     assert d["c5_scan_ref"]["nonunitary_proposals"]["settled"].startswith("on the device")
     fr = d["c4_bulk"]["with_status_through_the_failing_region"]
     assert fr["evals_per_s"] > 3e8 and 0.1 < fr["nonunitary_fraction"] < 0.3          # round 2: 1.5e8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_line_of_several_ranks_on_one_gpu(world, tmp_path):
+    """The N > 1 line through the real command and launcher, `world` ranks on the ONE GPU (GF_BENCH_DEVICE=0), scans at a reduced
+    chain length: RCCL refuses the duplicate device (reported, exit status 3, as designed), the ranks fall back to hipIpc for the
+    device path, and the scans deliver as they would on `world` GPUs -- every rank reads its own chains back into the job's host
+    segment (`host_segment`), `d2h_links` == world with every rank's own byte count, and the device gather runs afterwards as a
+    sub-phase of its own whose result is checked against the segment.  What RCCL over xGMI does with N ranks this cannot show."""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, GF_BENCH_DEVICE="0", GF_RCCL_TIMEOUT="30", PYTHONDONTWRITEBYTECODE="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2",
+           "--cpu-sample", "20000", "--scan-burnin", "20", "--scan-nsteps", "40"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (res.returncode, res.stdout[-500:], res.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert res.returncode != 0 and "ncclCommInitRank" in d["rccl_error"]         # two ranks on one device: RCCL says no, the line says so
+    assert d["n_gpus"] == world and d["device_gather"] == "hipIpc" and d["rccl_nranks"] == [world] * world
+    assert d["host_segment"]["error"] is None and d["host_segment"]["bytes"] >= 256 * 512 * 40 * 12 * 8
+    n = d["config"]["evals_per_step_per_gpu"]
+    assert d["value"] == pytest.approx(world * n / (d["ms_per_step"] * 1e-3), rel=1e-6)   # the whole job: every rank's evaluations
+    for key, npts, per in (("c4_scan_ref", 64, 2048 * 40 * 9 * 8), ("c5_scan_ref", 256, 512 * 40 * 12 * 8)):
+        s = d[key]
+        assert "error" not in s and s["ranks"] == world and s["gather"].startswith("shared host segment")
+        assert s["d2h_links"] == world and s["gather_bytes"] == 0
+        from golemflavor_amd import dist as gdist
+        assert s["d2h_bytes_per_rank"] == [len(gdist.shard(npts, r, world)) * per for r in range(world)]
+        assert s["d2h_bytes"] == npts * per == s["chain_bytes_to_host"]        # the result, once: summed over the ranks' links
+        sub = s["device_gather_subphase"]
+        assert sub["kind"] == "hipIpc" and sub["verified"] is True and sub["comm_nranks"] == world
+        assert sub["bytes_into_root"] == sub["bytes_per_rank"] * (world - 1)
+        assert s["finite_fraction"] > 0.9
