@@ -175,9 +175,37 @@ GFX_HD inline dd dd_sqrt(dd a)
 }
 
 // ---- rounding to a 64-bit significand, ties to even ---------------------------------------------------
-// Branch-free since round 3: every + - * of the chain ends here, and the early returns of the first version (zero / inf / NaN,
-// out of the emulated range) put two or three divergent branches into each of them.  The general path is computed always and
-// the special cases are selected at the end; the results are unchanged bit for bit (tests/test_x87_emulation.py).
+// Every + - * of the chain ends here, and the arbitration kernels are bound by the number of instructions these primitives
+// are made of (profiles/r04/x87_integer_emulation_probe.txt: ~57 dependent instructions per multiply-add).
+// Round 3 made it branch-free; round 4 takes it down from ~21 instructions to 10 (GFX87_ROUND64_R3 keeps round 3's form for A/B):
+//   * the rounding constant c = 1.5 * 2^(e-11) is put together in the HIGH WORD of hi's own bit pattern: exponent field minus 11
+//     (minus 12 when the value lies in the binade below `hi`: hi a power of two and the tail of the other sign -- a zero tail of
+//     the other sign may take that branch too, it rounds to itself on any grid), top mantissa bit set: 32-bit operations only;
+//   * no special cases.  A signed maximum with zero turns the constant of everything below 2^-1011 (zeros included) into 0 or a
+//     denormal, and adding and subtracting that changes nothing: zeros and tiny numbers pass as they are.  For inf / NaN the constant
+//     is an ordinary number and the tail comes out NaN; round 3 returned (inf, 0) -- either way the residual ends as NaN, which the
+//     chain reports as +inf, fr.py's "not unitary" (an inf can only come from a division by an exact zero: fr.py:210, :232-236);
+//   * the pair is returned as (hi, rounded tail) WITHOUT the final renormalisation.  |tail| <= ulp(hi)/2 still holds (half an ulp is
+//     on the rounding grid), the VALUE is the same 64-bit number; only a tail of exactly half an ulp is no longer folded into hi.
+//     Nothing computes with the parts except through the error-free transformations, which do not care; x_ge compares by difference.
+// Results are unchanged as VALUES on everything finite (tests/test_x87_emulation.py compares the two forms on 48 M operand pairs
+// and whole chains; the device tests compare verdicts with the stored ones of round 3).
+#if !defined(GFX87_ROUND64_R3)
+GFX_HD inline x87 round64(dd v)
+{
+    const uint64_t b = (uint64_t)x_bits(v.hi);
+    const uint32_t hw = (uint32_t)(b >> 32), lw = (uint32_t)b;
+    const uint32_t tw = (uint32_t)((uint64_t)x_bits(v.lo) >> 32);
+    const bool below = (((hw & 0x000fffffu) | lw) == 0u) & ((int32_t)(hw ^ tw) < 0);
+    int32_t ch = (int32_t)((hw & 0x7ff00000u) + (below ? (0x00080000u - (12u << 20)) : (0x00080000u - (11u << 20))));
+    ch = ch > 0 ? ch : 0;
+    const double c = x_from_bits((int64_t)((uint64_t)(uint32_t)ch << 32));
+    x87 r;
+    r.hi = v.hi;
+    r.lo = (v.lo + c) - c;
+    return r;
+}
+#else
 GFX_HD inline x87 round64(dd v)
 {
     const int64_t b = x_bits(v.hi);
@@ -198,6 +226,7 @@ GFX_HD inline x87 round64(dd v)
     r.lo = special ? 0.0 : (tiny ? v.lo : ls);
     return r;
 }
+#endif
 
 GFX_HD inline dd as_dd(x87 a) { dd r = {a.hi, a.lo}; return r; }
 GFX_HD inline x87 x_from(double a) { x87 r = {a, 0.0}; return r; }
@@ -205,9 +234,25 @@ GFX_HD inline x87 x_neg(x87 a) { x87 r = {-a.hi, -a.lo}; return r; }
 GFX_HD inline x87 x_abs(x87 a) { return a.hi < 0.0 ? x_neg(a) : a; }
 GFX_HD inline double x_to_double(x87 a) { return a.hi + a.lo; }
 GFX_HD inline bool x_is_zero(x87 a) { return a.hi == 0.0; }
-GFX_HD inline bool x_ge(x87 a, x87 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
+// a >= b by the sign of the difference: the heads' difference is exact when they are close, and decides alone when they are not
+GFX_HD inline bool x_ge(x87 a, x87 b) { return (a.hi - b.hi) + (a.lo - b.lo) >= 0.0; }
 
+// The sum of two x87 NUMBERS (tails of at most 11 bits) needs less than the sum of two general double-doubles: the heads are added
+// exactly (two_sum), the tails and the heads' error in plain fp64.  a.lo + b.lo is exact unless the exponents lie more than
+// 41 apart, and then its rounding error is below 2^-106 of the result -- dd_add's own error class (its `e1 += s2` rounds in the same
+// place); under cancellation the heads' difference is exact and the tails' sum as well.  11 floating-point operations instead of 20.
+GFX_HD inline dd dd_add_x(x87 a, x87 b)
+{
+    double s, e;
+    two_sum(a.hi, b.hi, s, e);
+    e += a.lo + b.lo;
+    return dd_norm(s, e);
+}
+#if !defined(GFX87_ROUND64_R3)
+GFX_HD GFX_XOP x87 x_add(x87 a, x87 b) { return round64(dd_add_x(a, b)); }
+#else
 GFX_HD GFX_XOP x87 x_add(x87 a, x87 b) { return round64(dd_add(as_dd(a), as_dd(b))); }
+#endif
 GFX_HD inline x87 x_sub(x87 a, x87 b) { return x_add(a, x_neg(b)); }      // dd_sub is dd_add of the negation: the same operations
 GFX_HD GFX_XOP x87 x_mul(x87 a, x87 b) { return round64(dd_mul(as_dd(a), as_dd(b))); }
 GFX_HD GFX_BIG x87 x_div(x87 a, x87 b) { return round64(dd_div(as_dd(a), as_dd(b))); }

@@ -164,14 +164,18 @@ def test_large_reads_come_back_through_the_pinned_ring_intact():
             _lib.device_trim(0)                                  # frees the pinned slots too: the next large read allocates them again
 
 
-@pytest.mark.parametrize("case", ["sm_one_workgroup", "sm_grid", "sm_grid_through_the_ring", "sm_grid_one_wide_chain", "bsm_stacked"])
-def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden):
+@pytest.mark.parametrize("case", ["sm_one_workgroup", "sm_grid", "sm_grid_through_the_ring", "sm_grid_through_the_ring_block_pipelines",
+                                  "sm_grid_one_wide_chain", "bsm_stacked"])
+def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden, monkeypatch):
     """gf_sampler_run_to_host copies every finished block of steps to the host while the run goes on.  The result must be,
     bit for bit, what run_mcmc followed by the chain's read-back gives for the same seed: one-workgroup sampler (a single
     mark), the grid sampler (graph replays of 16 steps + an eager tail), stacked BSM chains with the settle step; with a
     stored prefix from an earlier run, with thinning, with the lnprob chain."""
     from golemflavor_amd import mcmc as mcmc_utils
     rng = np.random.default_rng(9)
+    if case.endswith("_block_pipelines"):           # round 4: one read-back pipe per run is the default; the A/B switch gives each block its own
+        monkeypatch.setenv("GF_RUN_TO_HOST_NO_PIPE", "1")
+        case = case[:-len("_block_pipelines")]
     if case == "bsm_stacked":
         asimov, ps = Cf.fr_paramsets(6, fr_utils.fr_to_angles((1, 1, 1)))
         fs = []

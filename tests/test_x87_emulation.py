@@ -47,6 +47,52 @@ def test_basic_operations_are_bit_exact(x87lib):
         assert list(cnt) == [0, 0, 0, 0, 0], list(cnt)
 
 
+def test_round4_primitives_equal_round3s(x87lib, tmp_path):
+    """Round 4 shortened the two primitives every emulated + - * is made of (round64 without selects, the sum of two x87 numbers
+    in 11 floating-point operations instead of 20; gf_x87.hpp).  Both forms on the same 48 M operand pairs -- random, cancelling,
+    ties and near-ties 42-64 binades apart, sums under a power of two, short significands: the same digest of all results, and
+    not one result that differs from the x87 unit's."""
+    out = str(tmp_path / "libx87host_r3.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-fPIC", "-shared", "-ffp-contract=off", "-DGFX87_ROUND64_R3", "-o", out,
+                           os.path.join(ROOT, "tests", "x87", "x87_host.cpp")])
+    old = C.CDLL(out)
+    for L in (x87lib, old):
+        L.x87t_digest.restype = C.c_uint64
+        L.x87t_digest.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]
+    for seed in (5, 6, 7):
+        w_new, w_old = C.c_int64(-1), C.c_int64(-1)
+        d_new = x87lib.x87t_digest(seed, 16_000_000, C.byref(w_new))
+        d_old = old.x87t_digest(seed, 16_000_000, C.byref(w_old))
+        assert w_new.value == 0 and w_old.value == 0, (seed, w_new.value, w_old.value)
+        assert d_new == d_old, seed
+
+
+def test_round4_chain_residuals_equal_round3s(golden, x87lib, tmp_path):
+    """The same A/B through the whole chain (angles_to_u with the emulated functions, both sandwiches, the Cardano chain, |X X^+|):
+    the residual of 160 G17 rows x 20 energy bins, bit for bit the same double from both forms of the primitives."""
+    out = str(tmp_path / "libx87host_r3.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-fPIC", "-shared", "-ffp-contract=off", "-DGFX87_ROUND64_R3", "-o", out,
+                           os.path.join(ROOT, "tests", "x87", "x87_host.cpp")])
+    old = C.CDLL(out)
+    old.x87t_bin_residual.restype = C.c_double
+    old.x87t_bin_residual.argtypes = x87lib.x87t_bin_residual.argtypes
+    rows = golden["g17_rows"]
+    centres = np.sqrt(BIN_EDGES[:-1] * BIN_EDGES[1:])
+    rng = np.random.default_rng(3)
+    n = big = 0
+    for i in rng.permutation(len(rows))[:160]:
+        r = rows[i]
+        dim, tex, th = int(r[0]), int(r[1]), r[2:]
+        sc2 = math.pow(10., th[6])
+        for e in centres:
+            a = x87lib.x87t_bin_residual(_arr(th[:4]), _arr(TEX[tex]), th[4], th[5], sc2, e, dim, None, None)
+            b = old.x87t_bin_residual(_arr(th[:4]), _arr(TEX[tex]), th[4], th[5], sc2, e, dim, None, None)
+            assert a == b or (a != a and b != b), (i, e, a, b)
+            n += 1
+            big += int(a > 1e-12)
+    assert n == 3200 and big > 1000
+
+
 def test_functions_are_correctly_rounded_neighbours_of_libm(x87lib):
     """asinl, acosl, sinl, cosl, hypotl: the emulation evaluates to ~2^-100 and rounds; glibc / the x87 microcode are
     faithful (< 1 ulp).  They must never differ by more than one unit in the last place, and agree in most calls."""

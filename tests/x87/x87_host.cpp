@@ -61,6 +61,57 @@ int x87t_arith(uint64_t seed, int n, int64_t* counts)
     return 0;
 }
 
+// A stream of + - * results folded into one 64-bit digest, and the number of them that differ from the x87 unit's: the two forms
+// of round64 / x_add (round 4's and -DGFX87_ROUND64_R3) must give the same digest.  Operands: as x87t_arith's, plus the cases the
+// short sum has to get right -- exponents 42 .. 64 apart with exact half-ulp ties and near-ties, sums that cancel into the binade below
+// a power of two, short significands, results that are powers of two.
+static inline uint64_t fold(uint64_t h, x87 r)          // of the VALUE (the pair need not be the canonical split of it)
+{
+    ld v = to_ld(r);
+    if (v == 0.0L) v = 0.0L;                            // the sign of a zero is not part of the digest
+    uint64_t m = 0, e = 0;
+    memcpy(&m, &v, 8); memcpy(&e, (const char*)&v + 8, 2);
+    h = (h ^ m) * 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+    h = (h ^ e) * 0xBF58476D1CE4E5B9ull; h ^= h >> 31;
+    return h;
+}
+uint64_t x87t_digest(uint64_t seed, int64_t n, int64_t* wrong)
+{
+    uint64_t s = seed, h = 0;
+    *wrong = 0;
+    for (int64_t it = 0; it < n; ++it) {
+        ld a, b;
+        const int kind = (int)(it % 12);
+        if (kind == 0) { a = rnd_ld(s, 40); b = a * (1.0L + ldexpl((ld)(sm64(s) % 4096), -60)); b = -b; }
+        else if (kind == 1) { a = rnd_ld(s, 2); b = (ld)(1 + sm64(s) % 60); }
+        else if (kind == 2) { a = rnd_ld(s, 5); b = rnd_ld(s, 5) * ldexpl(1.0L, -(int)(sm64(s) % 80)); }
+        else if (kind == 3) { a = (ld)(double)rnd_ld(s, 30); b = (ld)(double)rnd_ld(s, 30); }
+        else if (kind == 4) {                                            // b = (odd k) half-ulps of a, 42 .. 64 binades down: exact ties
+            a = rnd_ld(s, 20);
+            int ea; frexpl(a, &ea);
+            const int d = 42 + (int)(sm64(s) % 23);
+            b = ldexpl((ld)(2 * (sm64(s) % 2048) + 1), ea - 1 - d - 11);
+            if (sm64(s) & 1) b = -b;
+        }
+        else if (kind == 5) {                                            // half an ulp of a, 2^-36 of itself off the tie (a tie missed by
+            a = rnd_ld(s, 20);                                           // 2^-64 of b is beyond ANY double-double: the header's 2^-104)
+            int ea; frexpl(a, &ea);
+            b = ldexpl(1.0L, ea - 65);
+            b += (sm64(s) & 1) ? ldexpl(b, -36) : -ldexpl(b, -36);
+            if (sm64(s) & 1) b = -b;
+        }
+        else if (kind == 6) { a = ldexpl(1.0L, (int)(sm64(s) % 41) - 20); b = -rnd_ld(s, 30) * ldexpl(1.0L, -(int)(40 + sm64(s) % 50)); }   // under a power of two
+        else if (kind == 7) { a = (ld)(sm64(s) % 4096) * ldexpl(1.0L, (int)(sm64(s) % 9) - 4); b = (ld)(sm64(s) % 4096) - 2048; }        // short, zeros
+        else if (kind == 8) { a = rnd_ld(s, 3); b = ldexpl(1.0L, (int)(sm64(s) % 7) - 3) - a; }                                            // a + b = a power of two
+        else { a = rnd_ld(s, 60); b = rnd_ld(s, 60); }
+        const x87 xa = from_ld(a), xb = from_ld(b);
+        const x87 r0 = x_add(xa, xb), r1 = x_sub(xa, xb), r2 = x_mul(xa, xb);
+        h = fold(fold(fold(h, r0), r1), r2);
+        *wrong += !same(to_ld(r0), a + b) + !same(to_ld(r1), a - b) + !same(to_ld(r2), a * b);
+    }
+    return h;
+}
+
 // functions: exact[k] = calls whose emulated result equals libm's bit for bit, off1[k] = off by one ulp, worse[k] = more;
 // k = 0 asinl, 1 acosl, 2 sinl, 3 cosl, 4 hypotl
 int x87t_funcs(uint64_t seed, int n, int64_t* exact, int64_t* off1, int64_t* worse)
