@@ -57,6 +57,15 @@
 #define GFX_ROLLED
 #endif
 
+// The series of dd_sincos / dd_sin_small are the exception (round 4): rolled, every Horner step fetched its coefficient with a scalar
+// load and waited for it -- ~30 round trips to the constant cache per call, one of them for a single fused multiply-add in the fp64
+// tails.  They are out-of-line functions (one copy each), so unrolling them costs 2 KB of code and turns the table into literals.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GFX87_SERIES_ROLLED)
+#define GFX_SERIES _Pragma("unroll")
+#else
+#define GFX_SERIES GFX_ROLLED
+#endif
+
 // A/B switches for the arbitration kernels (tools/build_variants.sh): the complex / scalar primitives out of line
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GFX87_CMUL_NOINLINE)
 #define GFX_CMUL __attribute__((noinline))
@@ -143,6 +152,24 @@ GFX_HD inline dd dd_mul_d(dd a, double b)
     return dd_norm(p, e);
 }
 
+// c * t + k for Horner's rule when |k| >= |c t| (the series below: every coefficient is at least twice the product it is added
+// to) and the two do not cancel: the product is not normalised on its own, the heads are added by the three-operation sum that
+// needs the larger operand first, the tails in plain fp64 -- 14 operations instead of dd_mul + dd_add's 29, the same ~2^-104.
+GFX_HD inline dd dd_horner(dd c, dd t, dd k)
+{
+#if defined(GFX87_ROUND64_R3)
+    return dd_add(dd_mul(c, t), k);
+#endif
+    double p, e;
+    two_prod(c.hi, t.hi, p, e);
+    double u = c.hi * t.lo;
+    u = x_fma(c.lo, t.hi, u);
+    const double s = k.hi + p;
+    double r = p - (s - k.hi);
+    r += (k.lo + e) + u;
+    return dd_norm(s, r);
+}
+
 GFX_HD inline dd dd_div(dd a, dd b)
 {
     const double q1 = a.hi / b.hi;
@@ -196,7 +223,11 @@ GFX_HD inline x87 round64(dd v)
     const uint64_t b = (uint64_t)x_bits(v.hi);
     const uint32_t hw = (uint32_t)(b >> 32), lw = (uint32_t)b;
     const uint32_t tw = (uint32_t)((uint64_t)x_bits(v.lo) >> 32);
-    const bool below = (((hw & 0x000fffffu) | lw) == 0u) & ((int32_t)(hw ^ tw) < 0);
+    uint32_t sx = hw ^ tw;                                                          // bit 31: the signs of hi and of the tail differ
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(sx));                          // (keeps the compiler from widening the sign test into a 64-bit xor + compare)
+#endif
+    const bool below = (((hw & 0x000fffffu) | lw) == 0u) & ((int32_t)sx < 0);
     int32_t ch = (int32_t)((hw & 0x7ff00000u) + (below ? (0x00080000u - (12u << 20)) : (0x00080000u - (11u << 20))));
     ch = ch > 0 ? ch : 0;
     const double c = x_from_bits((int64_t)((uint64_t)(uint32_t)ch << 32));
@@ -305,21 +336,21 @@ GFX_HD GFX_BIG void dd_sincos(dd x, dd& sn, dd& cs)
     // sin r = r S(t),  S = sum_k (-1)^k t^k / (2k+1)!,  k = 0 .. 14;   cos r = C(t),  C = sum_k (-1)^k t^k / (2k)!,  k = 0 .. 14
     // fp64 tails: S from k = 8 (t^8 / 17! < 2^-54), C from k = 9 (t^9 / 18! < 2^-58)
     double ts = F[29].hi, tc = -F[28].hi;
-    GFX_ROLLED
+    GFX_SERIES
     for (int k = 13; k >= 8; --k) ts = x_fma(ts, t.hi, (k & 1) ? -F[2 * k + 1].hi : F[2 * k + 1].hi);
     tc = x_fma(tc, t.hi, F[26].hi);                                            // k = 13
-    GFX_ROLLED
+    GFX_SERIES
     for (int k = 12; k >= 9; --k) tc = x_fma(tc, t.hi, (k & 1) ? -F[2 * k].hi : F[2 * k].hi);
     dd s = dd_from(ts), c = dd_from(tc);
-    GFX_ROLLED
+    GFX_SERIES
     for (int k = 8; k >= 0; --k) {
         const ddc fc = F[2 * k];
         const dd ck = {(k & 1) ? -fc.hi : fc.hi, (k & 1) ? -fc.lo : fc.lo};
-        c = dd_add(dd_mul(c, t), ck);
+        c = dd_horner(c, t, ck);
         if (k < 8) {
             const ddc fs = F[2 * k + 1];
             const dd sk = {(k & 1) ? -fs.hi : fs.hi, (k & 1) ? -fs.lo : fs.lo};
-            s = dd_add(dd_mul(s, t), sk);
+            s = dd_horner(s, t, sk);
         }
     }
     s = dd_mul(s, r);
@@ -337,14 +368,14 @@ GFX_HD GFX_BIG dd dd_sin_small(dd x)
     static const ddc F[30] = {GFX_INV_FACT_TABLE};
     const dd t = dd_mul(x, x);
     double ts = F[29].hi;
-    GFX_ROLLED
+    GFX_SERIES
     for (int k = 13; k >= 8; --k) ts = x_fma(ts, t.hi, (k & 1) ? -F[2 * k + 1].hi : F[2 * k + 1].hi);
     dd v = dd_from(ts);
-    GFX_ROLLED
+    GFX_SERIES
     for (int k = 7; k >= 0; --k) {
         const ddc fs = F[2 * k + 1];
         const dd sk = {(k & 1) ? -fs.hi : fs.hi, (k & 1) ? -fs.lo : fs.lo};
-        v = dd_add(dd_mul(v, t), sk);
+        v = dd_horner(v, t, sk);
     }
     return dd_mul(v, x);
 }
@@ -415,7 +446,7 @@ GFX_HD inline double cr_pow10(double x)
     for (int k = 11; k >= 0; --k) {
         const ddc fk = F[k];
         const dd ck = {fk.hi, fk.lo};
-        sum = dd_add(dd_mul(sum, z), ck);
+        sum = dd_horner(sum, z, ck);
     }
     return ldexp(sum.hi, (int)n);                                     // sum.hi = fl(sum): the nearest double
 }
