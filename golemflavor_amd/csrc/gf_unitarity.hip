@@ -41,7 +41,7 @@ using namespace gfx87;
 // failing energy) or none is left; then it fetches the next walker.  Every wave leaves when the queue is exhausted and all its
 // groups have finished their walker: the exit condition is reached whatever the other waves do.
 template <class Team>
-__global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
+__global__ __launch_bounds__(UNI_BLOCK, GF_UNI_RESOLVE_WAVES) void k_uni_resolve(const GfCommon* __restrict__ cp, const GfBsm* __restrict__ tbp,
                                                            const double* __restrict__ theta, int layout, int64_t n,
                                                            double* __restrict__ lnprob, int32_t* __restrict__ status,
                                                            GfArbQueue* __restrict__ uq, GfUniQueue* __restrict__ wq, unsigned int* __restrict__ seen)
@@ -174,16 +174,17 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
     unsigned int parts = 1;
     bool exhausted = !active, failed = false, mine = false;             // mine: this group holds a part whose end it must report
     unsigned int warm = 0u;
+    // The parts are handed out by position, not by a counter: group G of the grid takes the slots G, G + (groups of the grid), ...
+    // The queue is short (its slots rarely outnumber the groups) and a half-step waits for the LAST part, so there is no balance to
+    // gain from fetching dynamically -- and the fetch was an atomic with a return on the path every part waits for (~2 us of 47).
+    const unsigned long long total_groups = (unsigned long long)gridDim.x * (UNI_BLOCK / 64) * Team::PER_WAVE;
+    unsigned long long next = ((unsigned long long)blockIdx.x * (UNI_BLOCK / 64) + (unsigned long long)wave) * Team::PER_WAVE + (unsigned long long)grp;
     for (;;) {
         const bool need = !exhausted && !mine;
-        const unsigned long long nb = __ballot(need && lead);
-        if (nb != 0ull) {
-            unsigned int base = 0;
-            const int leader = __ffsll((long long)nb) - 1;
-            if (lane == leader) base = atomicAdd(&uq->head, (unsigned int)__popcll(nb));
-            base = (unsigned int)__shfl((int)base, leader);
+        if (__ballot(need) != 0ull) {
             if (need) {
-                const unsigned int idx = base + (unsigned int)__popcll(nb & ((1ull << (grp * Team::LANES)) - 1ull));
+                const unsigned long long idx = next;
+                next += total_groups;
                 if (idx < vcount) {
                     const GfArbItem it = uq->items[idx / fan];
                     t = (int64_t)it.walker;
@@ -233,15 +234,20 @@ __global__ __launch_bounds__(UNI_BLOCK, GF_UNI_WAVES) void k_stretch_settle(cons
                 mine = false;
                 if (lead) {
                     // report this part; the last part of the walker to report completes the walker's half-step
-                    // (gf_sampler.hip stretch_body, after proposal_lnprob)
-                    if (failed) atomicOr(&s.ctl[2 * t + 1], 1u);
-                    __threadfence();
-                    const unsigned int before = atomicAdd(&s.ctl[2 * t], 1u);
-                    if (before == parts - 1u) {
+                    // (gf_sampler.hip stretch_body, after proposal_lnprob).  A walker in ONE part has nobody to meet: no counters.
+                    bool last = parts == 1u, bad = failed;
+                    if (!last) {
+                        if (failed) atomicOr(&s.ctl[2 * t + 1], 1u);
                         __threadfence();
-                        const bool bad = atomicOr(&s.ctl[2 * t + 1], 0u) != 0u;
-                        s.ctl[2 * t] = 0u;                              // zero between uses
-                        s.ctl[2 * t + 1] = 0u;
+                        last = atomicAdd(&s.ctl[2 * t], 1u) == parts - 1u;
+                        if (last) {
+                            __threadfence();
+                            bad = atomicOr(&s.ctl[2 * t + 1], 0u) != 0u;
+                            s.ctl[2 * t] = 0u;                          // zero between uses
+                            s.ctl[2 * t + 1] = 0u;
+                        }
+                    }
+                    if (last) {
                         const double* row = s.pend_rows + (size_t)t * GF_PEND_STRIDE;
                         const int kk = (int)(t - (int64_t)chain * nhalf);
                         const int w = s.half * nhalf + kk;

@@ -24,8 +24,11 @@ constexpr int UNI_BLOCK = 128;
 #ifndef GF_UNI_WAVES
 #define GF_UNI_WAVES 2                                // waves per SIMD k_uni_resolve is compiled for (~245 VGPRs)
 #endif
+#ifndef GF_UNI_RESOLVE_WAVES
+#define GF_UNI_RESOLVE_WAVES GF_UNI_WAVES             // the bulk arbitration kernel alone (throughput), apart from the settle step (latency)
+#endif
 #ifndef GF_UNI_BLOCKS_PER_CU
-#define GF_UNI_BLOCKS_PER_CU (GF_UNI_WAVES * 4 * 64 / UNI_BLOCK)    // what is resident at once: later blocks would find the queue empty
+#define GF_UNI_BLOCKS_PER_CU (GF_UNI_RESOLVE_WAVES * 4 * 64 / UNI_BLOCK)    // what is resident at once: later blocks would find the queue empty
 #endif
 
 // `ndim`: the row stride of an AoS block (the sampler's parked proposals are rows of GF_PEND_STRIDE doubles)
