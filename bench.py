@@ -434,6 +434,12 @@ def extra_scan(device, config, burnin, nsteps, rank=0, world=1, control=None, rc
                                   gather_kind=gather_kind, rccl_init_s=rccl_init_s, chain_bytes_to_host=nbytes,
                                   finite_fraction=finite, nonunitary=dict(scan.LAST_NONUNITARY) if scan.LAST_NONUNITARY else None)
     rec["d2h_links"] = int(np.count_nonzero(per_rank[:, 1] > 0)) if world > 1 else 1
+    if world == 1:
+        ar = scan._ARENA.get("arena")
+        rec["destination"] = ("registered result arena (DMA straight into it)" if ar is not None and ar.registered and ar.nbytes >= nbytes else
+                              "fresh memory on 2 MiB pages, through the pinned ring and the host's copy threads")
+    elif isinstance(g, scan.SharedHostGather) and g.seg is not None:
+        rec["destination"] = "host segment%s" % (", registered by every rank (DMA straight into it)" if getattr(g.seg, "_registered", None) else "")
     rec["d2h_s_per_rank"] = [round(float(x), 4) for x in per_rank[:, 0]]
     rec["d2h_bytes_per_rank"] = [int(x) for x in per_rank[:, 1]]
     rec["sampling_s_per_rank"] = [round(float(x), 4) for x in per_rank[:, 2]]
@@ -729,6 +735,28 @@ def run(a, json_out):
 
     # sub-records.  The sharded scans run on EVERY rank (rank 0 assembles); the rest is rank 0's
     extras = {}
+    # Where the scans' results go: memory REGISTERED with the HIP runtime once per job, so that every read-back is a DMA straight into
+    # it at the speed of the link (gf_host_register, ABI 5; profiles/r04/host_register.txt) -- at N > 1 every rank registers its
+    # mapping of the job's host segment, at N = 1 a process-lifetime arena (scan.ResultArena).  Set up here, outside every timed
+    # region, and reported (`host_segment` / `result_arena`); what a scan costs into FRESH memory is reported beside it at N = 1.
+    result_arena = None
+    if not a.no_extras and not os.environ.get("GF_BENCH_NO_ARENA"):
+        from golemflavor_amd import scan as _scan
+        if arena is not None and arena.error is None:
+            ok, secs = arena.register()
+            regs = control.allgather(np.array([1.0 if ok else 0.0, secs], dtype=np.float64))
+            host_segment["registered_ranks"] = int(regs[:, 0].sum())
+            host_segment["register_s"] = round(float(regs[:, 1].max()), 4)
+            if getattr(arena, "register_error", None):
+                host_segment["register_error"] = arena.register_error
+        elif world == 1:
+            need = max(_scan.segment_bytes(64, 1, 2048, max(a.scan_nsteps, 200), 9), _scan.segment_bytes(256, 1, 512, max(a.scan_nsteps, 200), 12))
+            result_arena = _scan.ResultArena(need)
+            _scan.set_result_arena(result_arena)
+            extras["result_arena"] = {"bytes": int(result_arena.nbytes), "registered": bool(result_arena.registered),
+                                      "set_up_s": round(result_arena.seconds, 4), "error": result_arena.register_error,
+                                      "note": "one registered block of host memory for the job's scans (2 MiB pages, mapped and pinned "
+                                              "once, outside every timed region): their read-backs are DMA straight into it"}
 
     def guarded(key, fn, collective=False):
         try:
@@ -756,6 +784,17 @@ def run(a, json_out):
         for key, cfg in (("c4_scan_ref", "C4"), ("c5_scan_ref", "C5")):
             guarded(key, lambda cfg=cfg: extra_scan(local_rank, cfg, a.scan_burnin, a.scan_nsteps, rank, world, control, rccl,
                                                     rccl_init_s, shared, arena), collective=True)
+        if result_arena is not None:
+            # the same two scans into FRESH memory (what a process pays that produces one result and exits)
+            _scan.set_result_arena(None)
+            for key, cfg in (("c4_scan_ref", "C4"), ("c5_scan_ref", "C5")):
+                if isinstance(extras.get(key), dict) and "error" not in extras[key]:
+                    try:
+                        r = extra_scan(local_rank, cfg, a.scan_burnin, a.scan_nsteps)
+                        extras[key]["seconds_into_fresh_memory"] = r["seconds"]
+                    except Exception as exc:   # noqa: BLE001
+                        extras[key]["seconds_into_fresh_memory"] = "%s: %s" % (type(exc).__name__, exc)
+            result_arena.close()
         if host_segment is not None:
             extras["host_segment"] = host_segment
 

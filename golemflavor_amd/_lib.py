@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOLEMHIP_LIB") or os.path.join(HERE, "libgolemhip.so")   # override: kernel A/B experiments
 
-GF_ABI_VERSION = 4
+GF_ABI_VERSION = 5
 GF_MAX_DIM = 16
 GF_MAX_BINS = 64
 GF_COMM_ID_BYTES = 128
@@ -117,6 +117,8 @@ SIGNATURES = {
     "gf_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "gf_host_prepare": (C.c_int, [_vp, C.c_size_t]),
     "gf_host_prepare_n": (C.c_int, [_vp, C.c_size_t, C.c_int]),
+    "gf_host_register": (C.c_int, [_vp, C.c_size_t]),
+    "gf_host_unregister": (C.c_int, [_vp]),
     "gf_sampler_set_stream_ids": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "gf_sampler_get_chain_device": (C.c_int, [_vp, _vp, _vp]),
     "gf_sampler_postprocess_device": (C.c_int, [_vp, C.POINTER(_vp), _vp, _vp]),

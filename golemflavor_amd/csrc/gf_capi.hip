@@ -23,6 +23,7 @@
 #include "../../include/golemflavor_hip.h"
 #include "gf_consts.h"
 #include "gf_launch.h"
+#include "gf_devcache.h"                // large device allocations are cached, not handed back to the driver (hipMalloc / hipFree are macros from here on)
 
 static_assert(GF_MAX_DIM == 16 && GF_MAX_BINS == 64, "header / device constant mismatch");
 
@@ -191,6 +192,7 @@ struct DevicePool {
     int state = 0;                 // 0 unknown, 1 gfx950, -1 something else
     int cus = 256;
     std::vector<hipStream_t> streams;
+    std::vector<hipStream_t> copy_streams;               // high-priority streams for the large read-backs (pool_copy_stream)
     std::vector<void*> blocks;
     std::unordered_map<hipStream_t, UniWork*> work;      // never erased while the stream lives
 };
@@ -233,6 +235,29 @@ hipError_t pool_stream(int device, hipStream_t* stream)
         if (!dp.streams.empty()) { *stream = dp.streams.back(); dp.streams.pop_back(); }
     }
     return *stream ? hipSuccess : hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+}
+
+// A stream for a read-back that is to run BESIDE kernels of another stream.  The runtime multiplexes its streams onto a handful of
+// hardware queues (four by default), round-robin: a copy stream that lands on the compute stream's queue has its copies -- their
+// barrier packets -- queued BEHIND every kernel already enqueued there, and "post-process group by group while the finished groups cross
+// PCIe" silently becomes "post-process everything, then copy" (measured: C4's 9.4 GB of rows 0.18 s when the two streams sat on
+// different queues, 0.31 s = the sum of both when they shared one; which of the two a run got depended on how many streams the process
+// had created before: profiles/r04/host_register.txt).  Streams of another PRIORITY get hardware queues of their own, so the copy
+// streams are created with the greatest priority and kept in a pool of their own.
+hipError_t pool_copy_stream(int device, hipStream_t* stream)
+{
+    *stream = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevicePool& dp = g_pool[device];
+        if (!dp.copy_streams.empty()) { *stream = dp.copy_streams.back(); dp.copy_streams.pop_back(); }
+    }
+    if (*stream) return hipSuccess;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    static const bool plain = gf_internal_env("GF_COPY_STREAM_PLAIN", 0) != nullptr;            // A/B: a stream like any other
+    return (plain || least == greatest) ? hipStreamCreateWithFlags(stream, hipStreamNonBlocking)
+                                        : hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
 }
 
 hipError_t pool_block(int device, void** block)
@@ -830,6 +855,22 @@ void gf_internal_return_stream(int device, void* stream)          // idle (synch
 {
     if (device >= 0 && device < POOL_MAX_DEVICES && stream) pool_release(device, (hipStream_t)stream, nullptr);
 }
+// internal: a stream for a large read-back that overlaps another stream's kernels (pool_copy_stream: hardware queues of its own)
+int gf_internal_borrow_copy_stream(int device, void** stream)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !stream) return GF_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    const hipError_t e = pool_copy_stream(device, &st);
+    if (e != hipSuccess) return hip_fail(e, "pool_copy_stream");
+    *stream = (void*)st;
+    return GF_OK;
+}
+void gf_internal_return_copy_stream(int device, void* stream)     // idle (synchronised) streams only
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !stream) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool[device].copy_streams.push_back((hipStream_t)stream);
+}
 
 // internal: while `on`, every arbitration launch on `stream` takes the full grid whatever the previous one found
 // (gf_launch_uni_resolve); a workspace is created if the stream has none yet
@@ -1193,6 +1234,77 @@ void copy_rows(char* dst, size_t dpitch, const char* src, size_t width, size_t n
     g_copy_pool->run(dst, dpitch, src, width, nrows);
 }
 void parallel_memcpy(char* dst, const char* src, size_t len) { copy_rows(dst, len, src, len, 1); }
+
+// Is the host range [p, p + span) REGISTERED memory (gf_host_register) or hipHostMalloc'ed -- memory the device can write itself?
+// Asked once per read-back call (two attribute queries: the first byte and the last); GF_NO_DIRECT_D2H=1: always "no" (A/B).
+// *alias: the device's address of p.
+bool host_range_is_pinned(const void* p, size_t span, void** alias = nullptr)
+{
+    if (!p || span == 0) return false;
+    static const bool off = gf_internal_env("GF_NO_DIRECT_D2H", 0) != nullptr;
+    if (off) return false;
+    const char* ends[2] = {static_cast<const char*>(p), static_cast<const char*>(p) + span - 1};
+    for (const char* q : ends) {
+        hipPointerAttribute_t a;
+        std::memset(&a, 0, sizeof(a));
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory: an error on some runtimes
+        if (a.type != hipMemoryTypeHost) return false;                                                 // ... hipMemoryTypeUnregistered on others
+    }
+    if (alias) {
+        *alias = nullptr;
+        if (hipHostGetDevicePointer(alias, const_cast<void*>(p), 0) != hipSuccess || !*alias) { (void)hipGetLastError(); return false; }
+    }
+    return true;
+}
+
+// Rows of device memory into registered host memory by a KERNEL that stores through the host memory's device alias.  Why not the
+// runtime's DMA: hipMemcpyAsync into registered memory runs at 54-57 GB/s from the FIRST large device allocation of a process and at
+// 30 GB/s from any later one (freed and allocated again, or just allocated after a free: tools/vram_realloc_probe.py -- every scan
+// after a process's first was in that state, which is where "the read-backs vary by box and run" came from), while 32 workgroups of
+// this kernel deliver 55-56 GB/s from either (tools/experiments/d2h_kernel_probe.hip; profiles/r04/host_register.txt).  A tile is
+// 256 lanes x 16 elements of one row; few workgroups on purpose: the link is the bound, and the sampler's kernels keep the GPU.
+extern "C++" {
+template <typename T>
+__global__ __launch_bounds__(256) void k_d2h_rows(T* __restrict__ dst, size_t dpitch_e, const T* __restrict__ src, size_t spitch_e,
+                                                  size_t width_e, size_t height)
+{
+    constexpr size_t TILE = 256 * 16;
+    const size_t tiles_per_row = (width_e + TILE - 1) / TILE, ntiles = tiles_per_row * height;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t r = t / tiles_per_row, c0 = (t - r * tiles_per_row) * TILE;
+        const T* s = src + r * spitch_e + c0;
+        T* d = dst + r * dpitch_e + c0;
+        const size_t n = width_e - c0 < TILE ? width_e - c0 : TILE;
+#pragma unroll 4
+        for (size_t i = threadIdx.x; i < n; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+    }
+}
+}  // extern "C++"
+typedef double gf_v2d __attribute__((ext_vector_type(2)));
+
+// enqueue on `st`: `height` rows of `width` bytes, `spitch` apart on the device, to the registered host rows `dpitch` apart behind
+// `dst_alias` (their device address).
+hipError_t enqueue_d2h_rows(hipStream_t st, void* dst_host, void* dst_alias, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height)
+{
+    // The runtime's DMA by default: it needs no compute unit, so it runs beside the sampler's and the post-processing kernels without
+    // costing them a dispatch (the copy kernel beside them: C5 89 -> 177 us per half-step, C4's rows 33 GB/s).  The kernel is the
+    // faster of the two only while the driver wipes freed memory with the DMA engine -- which the device cache (gf_devcache.h) now
+    // keeps from happening.  GF_D2H_KERNEL=1: the kernel (A/B).
+    static const bool dma = gf_internal_env("GF_D2H_KERNEL", 0) == nullptr;
+    const bool words = ((width | dpitch | spitch | (size_t)(uintptr_t)dst_alias | (size_t)(uintptr_t)src) & 7u) == 0;
+    if (dma || !words || !dst_alias)
+        return height == 1 ? hipMemcpyAsync(dst_host, src, width, hipMemcpyDeviceToHost, st)
+                           : hipMemcpy2DAsync(dst_host, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, st);
+    static const int blocks = [] { const char* v = gf_internal_env("GF_D2H_KERNEL_BLOCKS", 0); const int k = v ? std::atoi(v) : 0; return k >= 1 && k <= 4096 ? k : 32; }();
+    const bool wide = ((width | dpitch | spitch | (size_t)(uintptr_t)dst_alias | (size_t)(uintptr_t)src) & 15u) == 0;
+    if (wide)
+        hipLaunchKernelGGL(k_d2h_rows<gf_v2d>, dim3(blocks), dim3(256), 0, st, static_cast<gf_v2d*>(dst_alias), dpitch / 16,
+                           static_cast<const gf_v2d*>(src), spitch / 16, width / 16, height);
+    else
+        hipLaunchKernelGGL(k_d2h_rows<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(dst_alias), dpitch / 8,
+                           static_cast<const double*>(src), spitch / 8, width / 8, height);
+    return hipGetLastError();
+}
 }  // namespace
 
 // internal (also gf_sampler.hip): synchronous copy of `bytes` from device memory to any host memory, through the ring,
@@ -1205,6 +1317,22 @@ int gf_internal_d2h_gated(int device, void* stream, void* dst_host, const void* 
     if (device < 0 || device >= POOL_MAX_DEVICES || !dst_host || !src_dev) return GF_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     static const bool ring_off = gf_internal_env("GF_NO_D2H_PIPELINE", 0) != nullptr;            // diagnostics / A-B
+    void* alias = nullptr;
+    if (bytes >= D2H_RING_MIN && host_range_is_pinned(dst_host, bytes, &alias)) {
+        // a registered destination (gf_host_register): written directly (enqueue_d2h_rows), piece by piece as the source is completed
+        const size_t piece = (size_t)64 << 20;
+        for (size_t off = 0; off < bytes; off += piece) {
+            const size_t len = bytes - off < piece ? bytes - off : piece;
+            if (gate && gate(gate_ctx, off + len) != 0) {
+                (void)hipStreamSynchronize(st);
+                std::snprintf(g_err, sizeof(g_err), "gf_internal_d2h: the source was not completed");
+                return GF_ERR_HIP;
+            }
+            GF_HIP(enqueue_d2h_rows(st, static_cast<char*>(dst_host) + off, static_cast<char*>(alias) + off, len, static_cast<const char*>(src_dev) + off, len, len, 1));
+        }
+        GF_HIP(hipStreamSynchronize(st));
+        return GF_OK;
+    }
     if (bytes < D2H_RING_MIN || ring_off) {
         if (gate && gate(gate_ctx, bytes) != 0) return GF_ERR_HIP;
         GF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
@@ -1267,6 +1395,12 @@ int gf_internal_d2h_2d(int device, void* stream, void* dst_host, size_t dpitch, 
     const char* src = static_cast<const char*>(src_dev);
     if (width == dpitch && width == spitch) return gf_internal_d2h_gated(device, stream, dst_host, src_dev, width * height, nullptr, nullptr);
     static const bool ring_off = gf_internal_env("GF_NO_D2H_PIPELINE", 0) != nullptr;
+    void* alias = nullptr;
+    if (width * height >= D2H_RING_MIN && host_range_is_pinned(dst, (height - 1) * dpitch + width, &alias)) {
+        GF_HIP(enqueue_d2h_rows(st, dst, alias, dpitch, src, spitch, width, height));
+        GF_HIP(hipStreamSynchronize(st));
+        return GF_OK;
+    }
     if (width * height < D2H_RING_MIN || ring_off) {
         GF_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, st));
         GF_HIP(hipStreamSynchronize(st));
@@ -1329,6 +1463,7 @@ struct gf_d2h_pipe {
     std::atomic<size_t> issued{0}, drained{0};
     std::atomic<int> failed{0}, closing{0};
     std::thread consumer;
+    bool direct_pending = false;            // blocks went straight into a registered destination: _close waits for the stream
 };
 
 int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out)
@@ -1374,6 +1509,14 @@ int gf_internal_d2h_pipe_rows(gf_d2h_pipe* p, void* dst_host, size_t dpitch, con
     char* dst = static_cast<char*>(dst_host);
     const char* src = static_cast<const char*>(src_dev);
     hipError_t e = hipSuccess;
+    void* alias = nullptr;
+    if (host_range_is_pinned(dst, (height - 1) * dpitch + width, &alias)) {
+        // a registered destination: the block goes straight to where its rows belong (enqueue_d2h_rows) -- no slot, no host thread
+        e = enqueue_d2h_rows(p->st, dst, alias, dpitch, src, spitch, width, height);
+        if (e != hipSuccess) { p->failed.store(1); return hip_fail(e, "gf_internal_d2h_pipe_rows"); }
+        p->direct_pending = true;
+        return GF_OK;
+    }
     auto issue = [&](char* d, size_t dp, const char* sp, size_t spi, size_t w, size_t nr) {
         const size_t c = p->issued.load(std::memory_order_relaxed);
         while (c >= p->drained.load(std::memory_order_acquire) + D2H_SLOTS && !p->failed.load()) std::this_thread::yield();   // the slot is free
@@ -1403,6 +1546,7 @@ int gf_internal_d2h_pipe_close(gf_d2h_pipe* p)
     if (!p) return GF_OK;
     p->closing.store(1);
     if (p->consumer.joinable()) p->consumer.join();
+    if (p->direct_pending && hipStreamSynchronize(p->st) != hipSuccess) p->failed.store(1);
     const int bad = p->failed.load();
     p->ring->mu.unlock();
     delete p;
@@ -1590,6 +1734,20 @@ int gf_host_prepare_n(void* buf, size_t bytes, int threads)
     return GF_OK;
 }
 
+// ABI 5: a result arena -- host memory registered with the runtime, so that the read-backs' DMA writes it directly (host_range_is_pinned)
+int gf_host_register(void* buf, size_t bytes)
+{
+    if (!buf || bytes == 0) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipHostRegister(buf, bytes, hipHostRegisterPortable));
+    return GF_OK;
+}
+int gf_host_unregister(void* buf)
+{
+    if (!buf) return GF_ERR_INVALID_ARG;
+    GF_HIP(hipHostUnregister(buf));
+    return GF_OK;
+}
+
 int gf_model_sync(gf_model* m)
 {
     if (!m) return GF_ERR_INVALID_ARG;
@@ -1685,7 +1843,7 @@ int gf_device_trim(int device, size_t* released_bytes)
         }
         blocks.swap(dp.blocks);
     }
-    size_t total = 0;
+    size_t total = gf_devcache_trim(device);            // the cached large buffers (gf_devcache.h) go back to the driver too
     for (UniWork* w : idle) {
         std::lock_guard<std::mutex> lk(w->mu);
         total += w->bytes();

@@ -11,6 +11,7 @@
 #include <new>
 
 #include "../../include/golemflavor_hip.h"
+#include "gf_devcache.h"                // large device allocations are cached, not handed back to the driver (hipMalloc / hipFree are macros from here on)
 
 static_assert(GF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RCCL unique id size changed");
 

@@ -32,6 +32,7 @@ extern "C" const char* gf_internal_env(const char* name, int affects_results);  
 #include "gf_bsm_device.hpp"
 #include "gf_launch.h"
 #include "gf_unitarity_teams.hpp"      // Team9: the reference's unitarity chain on nine lanes (k_stretch_chain settles its own parked proposals)
+#include "gf_devcache.h"                // large device allocations are cached, not handed back to the driver (hipMalloc / hipFree are macros from here on)
 
 namespace {
 using namespace gfdev;
@@ -1338,7 +1339,11 @@ struct HostSink {
     int64_t copied = 0;                            // stored steps whose copy has been issued
     int rc = GF_OK;
     std::chrono::steady_clock::time_point last_event;   // when the newest consumed block was seen complete
+    // where the host thread's time went (diagnostics: gf_internal_run_to_host_times): [0] total / [1] longest call issuing a block's
+    // copy, [2] total / [3] longest wait for a block to complete, [4] blocks, [5] total / [6] longest enqueue of a block of steps
+    double t[8] = {};
 };
+double g_last_run_to_host_times[8] = {};
 
 // accessors implemented in gf_capi.hip (gf_model is private to it)
 extern "C" {
@@ -1351,6 +1356,8 @@ int gf_model_lnprob_on(gf_model* m, void* stream, const double* d_theta, int lay
                        double* d_fr, int32_t* d_status);
 void gf_internal_full_arbitration_grids(int device, void* stream, int on);
 int gf_internal_borrow_stream(int device, void** stream);
+int gf_internal_borrow_copy_stream(int device, void** stream);
+void gf_internal_return_copy_stream(int device, void* stream);
 void gf_internal_return_stream(int device, void* stream);
 int gf_model_propagate_on(gf_model* m, void* stream, const double* d_theta, int layout, int64_t n, double* d_fr,
                           int32_t* d_status);
@@ -1599,6 +1606,9 @@ int sink_copy(gf_sampler* s, int64_t upto)
     const size_t row = sizeof(double) * (size_t)s->nwalkers * s->ndim, lrow = sizeof(double) * (size_t)s->nwalkers;
     const size_t prev = (size_t)k->copied, now = (size_t)(upto - k->copied);
     int rc;
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Clock { HostSink* k; std::chrono::steady_clock::time_point t0;
+                   ~Clock() { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); k->t[0] += d; if (d > k->t[1]) k->t[1] = d; k->t[4] += 1.0; } } clock_{k, t_in};
     if (k->pipe) {
         rc = gf_internal_d2h_pipe_rows(k->pipe, reinterpret_cast<char*>(k->chain) + row * prev, row * (size_t)k->total,
                                        reinterpret_cast<const char*>(s->d_chain) + row * prev, row * (size_t)s->nstore_cap, row * now,
@@ -1626,7 +1636,12 @@ int sink_copy(gf_sampler* s, int64_t upto)
 hipError_t flight_consume(gf_sampler* s, bool wait)
 {
     const int slot = (int)(s->flight_done % gf_sampler::FLIGHT);
+    const auto t_w = std::chrono::steady_clock::now();
     hipError_t e = wait ? hipEventSynchronize(s->flight_ev[slot]) : hipEventQuery(s->flight_ev[slot]);
+    if (wait && s->sink) {
+        const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
+        s->sink->t[2] += d; if (d > s->sink->t[3]) s->sink->t[3] = d;
+    }
     if (e != hipSuccess) return e;                                  // hipErrorNotReady: still running
     if (s->sink) { s->sink->last_event = std::chrono::steady_clock::now(); (void)sink_copy(s, s->flight_nstored[slot]); }
     ++s->flight_done;
@@ -1927,7 +1942,12 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
         while (s->graph && nsteps - done >= GRAPH_STEPS) {
             hipError_t e = flight_admit(s);
             if (e != hipSuccess) return sfail(e, "block in flight");
+            const auto t_g = std::chrono::steady_clock::now();
             e = hipGraphLaunch(s->graph, st);
+            if (s->sink) {
+                const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_g).count();
+                s->sink->t[5] += d; if (d > s->sink->t[6]) s->sink->t[6] = d;
+            }
             if (e != hipSuccess) return sfail(e, "hipGraphLaunch");
             done += GRAPH_STEPS;
             e = flight_mark(s, st, store ? hs.store_base + (done + thin - 1) / thin : hs.store_base);
@@ -1970,7 +1990,7 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
     GFS_HIP(hipSetDevice(device));
     void* copy_stream = nullptr;
-    int rc = gf_internal_borrow_stream(device, &copy_stream);
+    int rc = gf_internal_borrow_copy_stream(device, &copy_stream);
     if (rc != GF_OK) return rc;
     // One thread, one pipeline: gf_sampler_run enqueues block after block and, between two blocks, hands every block the GPU has
     // finished meanwhile to the sink (flight_admit) -- at most FLIGHT blocks are ever enqueued ahead of the GPU, and the copies run
@@ -1981,7 +2001,7 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     sink.last_event = std::chrono::steady_clock::now();
     if (gf_internal_env("GF_RUN_TO_HOST_NO_PIPE", 0) == nullptr) {       // diagnostics / A-B: else every block is a read-back of its own
         rc = gf_internal_d2h_pipe_open(device, copy_stream, &sink.pipe);
-        if (rc != GF_OK) { gf_internal_return_stream(device, copy_stream); return rc; }
+        if (rc != GF_OK) { gf_internal_return_copy_stream(device, copy_stream); return rc; }
     }
     const bool marks = gf_internal_env("GF_RUN_TO_HOST_NO_MARKS", 0) == nullptr;      // diagnostics: no sink during the run = one copy after it
     s->sink = marks ? &sink : nullptr;
@@ -1998,9 +2018,10 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     }
     const int rc_pipe = gf_internal_d2h_pipe_close(sink.pipe);          // drains: every chunk is in the destination
     (void)hipStreamSynchronize((hipStream_t)copy_stream);
-    gf_internal_return_stream(device, copy_stream);
+    gf_internal_return_copy_stream(device, copy_stream);
     if (rc == GF_OK && sink.rc == GF_OK) sink.rc = rc_pipe;
     if (readback_tail_s) *readback_tail_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_done).count();
+    for (int i = 0; i < 8; ++i) g_last_run_to_host_times[i] = sink.t[i];
     if (rc != GF_OK) return rc;
     if (sink.rc != GF_OK) return sink.rc;
     if (e == hipSuccess) e = e2;
@@ -2018,6 +2039,14 @@ int gf_internal_sampler_chain_stats(gf_sampler* s, unsigned long long* out)
     if (gf_model_internal(s->model, &c, &tb, &ptab, &stream, &device) != GF_OK) return GF_ERR_INVALID_ARG;
     GFS_HIP(hipMemcpyAsync(out, s->d_chain_stats, sizeof(unsigned long long) * 8 * (size_t)s->nchains, hipMemcpyDeviceToHost, (hipStream_t)stream));
     GFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GF_OK;
+}
+
+// diagnostics (not part of the ABI): the host thread's times of the process's LAST gf_sampler_run_to_host (HostSink::t), seconds / counts
+int gf_internal_run_to_host_times(double out[8])
+{
+    if (!out) return GF_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = g_last_run_to_host_times[i];
     return GF_OK;
 }
 
@@ -2248,7 +2277,7 @@ int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* 
     if (e == hipSuccess) e = hipMalloc((void**)&d_st, sizeof(int32_t) * per_chain * s->nchains);
     if (e == hipSuccess) e = hipMalloc((void**)&d_rows, chain_bytes * s->nchains);
     for (int g = 0; g < ngroups && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&ev[g], hipEventDisableTiming);
-    if (e == hipSuccess) rc = gf_internal_borrow_stream(device0, &copy_stream);
+    if (e == hipSuccess) rc = gf_internal_borrow_copy_stream(device0, &copy_stream);
     if (e == hipSuccess && rc == GF_OK) {
         gf_internal_full_arbitration_grids(device0, stream, 1);      // see gf_sampler_postprocess_device
         for (int ch = 0; ch < s->nchains && rc == GF_OK && e == hipSuccess; ++ch) {
@@ -2280,7 +2309,7 @@ int gf_sampler_postprocess_rows(gf_sampler* s, gf_model* const* models, double* 
         }
     }
     const hipError_t e2 = hipStreamSynchronize(st);
-    if (copy_stream) { (void)hipStreamSynchronize((hipStream_t)copy_stream); gf_internal_return_stream(device0, copy_stream); }
+    if (copy_stream) { (void)hipStreamSynchronize((hipStream_t)copy_stream); gf_internal_return_copy_stream(device0, copy_stream); }
     for (int g = 0; g < ngroups; ++g) if (ev[g]) (void)hipEventDestroy(ev[g]);
     if (d_fr) (void)hipFree(d_fr);
     if (d_st) (void)hipFree(d_st);

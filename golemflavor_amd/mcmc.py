@@ -368,6 +368,20 @@ class DeviceEnsembleSampler:
             return None
         return {"shape": ("undecided", "per chain", "grid")[int(out[0])], "probe_us_per_16_steps": {"per chain": float(out[1]), "grid": float(out[2])}}
 
+    def run_to_host_times(self):
+        """Diagnostics: where the host thread's time went in the process's last `run_mcmc_to_host` -- seconds issuing the blocks'
+        copies (total, longest call), waiting for blocks to complete (total, longest), the number of blocks, and enqueueing the
+        blocks of steps (total, longest launch)."""
+        fn = getattr(self._L, "gf_internal_run_to_host_times", None)
+        if fn is None:
+            return None
+        out = (self._C.c_double * 8)()
+        fn.restype, fn.argtypes = self._C.c_int, [self._C.POINTER(self._C.c_double)]
+        if fn(out) != 0:
+            return None
+        return {"copy_issue_s": round(out[0], 4), "copy_issue_max_s": round(out[1], 4), "block_wait_s": round(out[2], 4), "block_wait_max_s": round(out[3], 4),
+                "blocks": int(out[4]), "launch_s": round(out[5], 4), "launch_max_s": round(out[6], 4)}
+
     def undecided_census(self):
         st = self.chain_stats()
         if st is None:

@@ -173,20 +173,76 @@ class _SensPoint:
         return samples
 
 
-_ARENA = {"array": None}
+class ResultArena:
+    """Host memory for MANY results: one block on 2 MiB pages, its pages mapped, registered with the HIP runtime (`gf_host_register`,
+    ABI 5) -- the DMA engines then write a scan's chain or rows straight into it at the speed of the PCIe link (57 GB/s on the
+    MI355X boxes) instead of through the pinned staging ring and the host's copy threads (28-47 GB/s into fresh pages, the rate
+    that bounded both scans at the reference's chain length; profiles/r04/host_register.txt).  Setting it up costs what mapping its
+    pages costs (~25 GB/s: 0.5 s for 12.6 GB), so it pays for a process that produces more than one result -- a job that scans a
+    grid batch by batch and writes every batch out (scan.py's --datadir loop), bench.py -- not for a single read-back.
+
+    The results handed out ALIAS the arena: the next scan overwrites the previous one's arrays (save or reduce them first).
+    `set_result_arena(arena)` makes `result_array` -- every one-rank scan's destination -- use it; a request that does not fit gets
+    fresh memory as before.  `close()` unregisters."""
+
+    def __init__(self, nbytes, register=True):
+        import time as _time
+        from . import _lib
+        t0 = _time.perf_counter()
+        self.array = empty_hugepages((max(int(nbytes), 8) // 8,))
+        self.registered, self.register_error = False, None
+        if register:
+            try:
+                _lib.check(_lib.lib().gf_host_register(self.array.ctypes.data, self.array.nbytes), "gf_host_register")
+                self.registered = True
+            except Exception as exc:       # noqa: BLE001  (RLIMIT_MEMLOCK, no GPU ...): an unregistered arena still saves the page faults
+                self.register_error = "%s: %s" % (type(exc).__name__, exc)
+        if not self.registered:
+            self.array[:: 4096 // 8] = 0.0                 # map the pages at least
+        self.seconds = _time.perf_counter() - t0
+
+    @property
+    def nbytes(self):
+        return 0 if self.array is None else int(self.array.nbytes)
+
+    def take(self, shape):
+        n = int(np.prod(shape, dtype=np.int64))
+        if self.array is None or n > self.array.size:
+            return None
+        return self.array[:n].reshape(shape)
+
+    def close(self):
+        if self.registered and self.array is not None:
+            try:
+                from . import _lib
+                _lib.lib().gf_host_unregister(self.array.ctypes.data)
+            except Exception:              # noqa: BLE001
+                pass
+        self.registered, self.array = False, None
+
+
+_ARENA = {"arena": None}
+
+
+def set_result_arena(arena):
+    """The arena `result_array` serves from (None: fresh memory per result, the default).  Returns the previous one."""
+    old, _ARENA["arena"] = _ARENA["arena"], arena
+    return old
 
 
 def result_array(shape):
-    """Host memory for a scan's result (GBs that a device-to-host copy is about to fill for the first time): backed by 2 MiB pages
-    where the kernel grants them (model.empty_hugepages; GF_SCAN_NO_HUGEPAGES=1: plain np.empty, the A/B of
-    profiles/r04/readback.txt).  GF_SCAN_ARENA=1 (experiments only: a later scan overwrites an earlier one's result): one
-    process-lifetime block, reused, so that the second scan of a process writes into pages that are already mapped."""
+    """Host memory for a scan's result (GBs that a device-to-host copy is about to fill): the process's `ResultArena` if one is set
+    and the result fits (registered memory: the copy is a DMA at link speed) -- GF_SCAN_ARENA=1 sets one up on first use, sized by
+    that use --; else fresh memory backed by 2 MiB pages where the kernel grants them (model.empty_hugepages; GF_SCAN_NO_HUGEPAGES=1:
+    plain np.empty, the A/B of profiles/r04/readback.jsonl)."""
     n = int(np.prod(shape, dtype=np.int64))
-    if os.environ.get("GF_SCAN_ARENA"):
-        a = _ARENA["array"]
-        if a is None or a.size < n:
-            a = _ARENA["array"] = (np.empty(n) if os.environ.get("GF_SCAN_NO_HUGEPAGES") else empty_hugepages((n,)))
-        return a[:n].reshape(shape)
+    arena = _ARENA["arena"]
+    if arena is None and os.environ.get("GF_SCAN_ARENA"):
+        arena = _ARENA["arena"] = ResultArena(n * 8)
+    if arena is not None:
+        a = arena.take(shape)
+        if a is not None:
+            return a
     return np.empty(shape) if os.environ.get("GF_SCAN_NO_HUGEPAGES") else empty_hugepages(shape)
 
 
@@ -217,15 +273,19 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         sampler = mcmc_utils.DeviceEnsembleSampler(first.nwalkers, first.ndim, [jobs[g].f for g in order], seed=seed,
                                                    stream_ids=order)
         sampler.on_nonunitary = "-inf"
+        PHASES["sampling: sampler created"] = time.perf_counter() - t0
         # burn-in: enqueued, and only then -- while the GPU works through it and this thread has nothing to launch or allocate --
         # the result array is allocated and its pages are mapped (the size is known; model.Prefaulted).  Many threads taking page
         # faults hold up this thread's launches and allocations (they share the address space's lock), so the mapping must not
         # run beside them: it is waited for before the stored run starts (gather.destination)
         sampler.run_async(np.stack([jobs[g].p0 for g in order]), burnin, storechain=False)
+        PHASES["sampling: burn-in enqueued"] = time.perf_counter() - t0
         if gather is not None:
             gather.prepare(first, len(order), len(points), nsteps)
+        PHASES["sampling: destination prepared"] = time.perf_counter() - t0
         sampler.wait()
         sampler.reset()
+        PHASES["sampling: burn-in done"] = time.perf_counter() - t0
         streamed = None
         if gather is not None and gather.streams_chain(first):
             # one rank, the chain is the result: its blocks of steps cross PCIe while the later ones are sampled
@@ -245,6 +305,10 @@ def run_points(points, indices, make, burnin, nsteps, stacked=True, seed=25, gat
         shape = sampler.launch_shape()
         if shape is not None:
             LAST_NONUNITARY["launch_shape"] = shape
+        if streamed is not None:
+            times = sampler.run_to_host_times()
+            if times is not None:
+                LAST_NONUNITARY["host_thread_times"] = times
         t0 = time.perf_counter()
         if gather is not None:
             out = gather.run(sampler, jobs, order, len(points), streamed=streamed)

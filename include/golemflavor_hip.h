@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 4
+#define GF_ABI_VERSION 5
 #define GF_MAX_DIM 16
 #define GF_MAX_BINS 64
 /* CP phases (dcp; the NP matrix's for texture NONE) must stay within +-GF_PHASE_MAX: range (sampled) or value
@@ -197,6 +197,15 @@ int gf_host_prepare(void* buf, size_t bytes);
 /* ABI 3.  The same with the number of threads chosen by the caller (<= 0: the default, up to 16): few threads when the mapping is to
  * run beside the caller's own launches and allocations, which many page-faulting threads hold up. */
 int gf_host_prepare_n(void* buf, size_t bytes, int threads);
+/* ABI 5.  A result ARENA: host memory of the caller's (a numpy array, a mapping of a shared segment) registered with the HIP runtime, so
+ * that the DMA engines write the large read-backs -- sampler.chain (golemflavor/mcmc.py:43), the scans' rows -- STRAIGHT into it at the
+ * speed of the PCIe link: no pinned staging ring, no host thread copying (57 GB/s against 28-47 through the ring on the boxes of the
+ * pool; profiles/r04/host_register.txt).  Registering maps and pins every page (untouched 2 MiB-page memory: ~25 GB/s, touched: at
+ * once; 4 KiB shared-memory pages ~11 GB/s), which is worth it for memory that receives MANY results: a process-lifetime arena
+ * (golemflavor_amd.scan.ResultArena), each rank's region of the host segment of a multi-rank job.  Every read-back entry point finds out
+ * by itself whether its destination is registered.  gf_host_unregister before the memory is freed or unmapped. */
+int gf_host_register(void* buf, size_t bytes);
+int gf_host_unregister(void* buf);
 
 /* HIP events on the model's stream (what bench.py times the kernel with) */
 int gf_event_create(void** ev);

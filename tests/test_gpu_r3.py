@@ -217,3 +217,43 @@ def test_run_to_host_returns_the_chain_of_the_plain_run(case, golden, monkeypatc
         a.close(); b.close()
     for f in fs:
         f.close()
+
+
+def test_read_backs_into_a_registered_arena_equal_those_through_the_ring(golden):
+    """ABI 5: a destination registered with the runtime (`gf_host_register`, scan.ResultArena) is written by the DMA engines directly --
+    no pinned ring, no host copy threads.  Every large read-back route must deliver the same bytes either way: a device buffer's
+    download (1-D, above the ring's threshold), the stored chain (`chain_to_host`: pitched, row = chain), the chain read back while
+    it is sampled (`run_mcmc_to_host`: one pitched block per 16 steps through the pipe), and post-processed rows (gated pipeline)."""
+    from golemflavor_amd import mcmc as mcmc_utils, scan
+    asimov, ps = Cf.notebook_paramsets(golden["g6_asimov_angles"])
+    f = llh_utils.notebook_ln_prob(asimov, ps)
+    nch, nw, nd, nsteps = 32, 4096, 6, 48                                        # 100 MB blocks of 16 steps: the ring's territory
+    box = np.array(ps.seeds, dtype=float)
+    p0 = np.random.default_rng(5).uniform(box[:, 0], box[:, 1], size=(nch, nw, nd))
+    arena = scan.ResultArena(nch * nsteps * nw * (3 + nd) * 8)
+    assert arena.registered, arena.register_error
+    try:
+        # 1-D download
+        m = f.model
+        src = np.random.default_rng(1).standard_normal(40 << 20 >> 3)
+        d = m.alloc(src.nbytes).upload(src)
+        got = d.download(src.shape, out=arena.take(src.shape))
+        assert np.array_equal(got.view(np.int64), src.view(np.int64)) and np.shares_memory(got, arena.array)
+        d.free()
+        # stored chain, streamed chain, rows
+        a, b = (mcmc_utils.DeviceEnsembleSampler(nw, nd, f, nchains=nch, seed=4) for _ in range(2))
+        for smp in (a, b):
+            smp.run_mcmc(p0, 20, storechain=False)
+            smp.reset()
+        want = a.run_mcmc_to_host(None, nsteps)                                     # fresh numpy memory: the ring
+        got = b.run_mcmc_to_host(None, nsteps, out=arena.take(want.shape))          # registered: direct
+        assert np.shares_memory(got, arena.array) and np.array_equal(got, want)
+        keep = got.copy()
+        assert np.array_equal(b.chain_to_host(arena.take(want.shape)), keep)
+        rows_want = a.postprocess_rows()
+        rows_got = b.postprocess_rows(out=arena.take(rows_want.shape))
+        assert np.shares_memory(rows_got, arena.array) and np.array_equal(rows_got, rows_want, equal_nan=True)
+        a.close(); b.close()
+    finally:
+        arena.close()
+    assert not arena.registered and arena.take((1,)) is None

@@ -455,3 +455,27 @@ print(grown, bool(np.array_equal(a, np.arange(a.size, dtype=np.float64))), "GF_P
     assert out.returncode == 0, out.stderr[-2000:]
     grown, same, echoed = out.stdout.split()
     assert int(grown) > 150 << 20 and same == "True" and echoed == "True"
+
+
+def test_result_arena_without_a_gpu_is_still_an_arena():
+    """scan.ResultArena (ABI 5): registration fails where there is no device -- reported, not raised --, the block's pages are mapped
+    instead, `result_array` serves from it what fits (views that ALIAS the arena) and fresh memory otherwise."""
+    from golemflavor_amd import scan
+    arena = scan.ResultArena(8 << 20)
+    try:
+        assert arena.nbytes == 8 << 20 and arena.seconds >= 0.0
+        if not arena.registered:
+            assert arena.register_error                                     # "GolemHipError: gf_host_register failed: ..." or no library
+        old = scan.set_result_arena(arena)
+        try:
+            a = scan.result_array((4, 1000, 8))
+            b = scan.result_array((2, 100))
+            assert np.shares_memory(a, arena.array) and np.shares_memory(b, a)      # the next result overwrites the previous one
+            big = scan.result_array((3 << 20,))                                  # 24 MB: does not fit
+            assert not np.shares_memory(big, arena.array) and big.shape == (3 << 20,)
+        finally:
+            scan.set_result_arena(old)
+        assert not np.shares_memory(scan.result_array((16,)), arena.array)
+    finally:
+        arena.close()
+    assert arena.take((1,)) is None and not arena.registered
