@@ -62,6 +62,15 @@ def test_bench_line_sub_records_at_reduced_scan_length():
         assert s["evals_per_s"] == pytest.approx(s["evals"] / s["seconds"])
         assert s["finite_fraction"] > 0.9
     assert d["c5_scan_ref"]["nonunitary_proposals"]["settled"].startswith("on the device")
+    # round 4 (ABI 5): the job's scans deliver into ONE block of host memory registered with the runtime before anything is timed;
+    # what the reference-length scans cost into fresh memory is reported beside them
+    ar = d["result_arena"]
+    assert ar["registered"] is True and ar["error"] is None and ar["bytes"] >= 256 * 512 * 200 * 12 * 8 and ar["set_up_s"] > 0
+    for key in ("c4_scan", "c5_scan", "c4_scan_ref", "c5_scan_ref"):
+        assert d[key]["destination"].startswith("registered result arena"), d[key]["destination"]
+    for key in ("c4_scan_ref", "c5_scan_ref"):
+        assert isinstance(d[key]["seconds_into_fresh_memory"], float) and d[key]["seconds_into_fresh_memory"] > 0
+    assert d["c5_scan_ref"]["nonunitary_proposals"]["host_thread_times"]["blocks"] >= 1
     fr = d["c4_bulk"]["with_status_through_the_failing_region"]
     assert fr["evals_per_s"] > 3e8 and 0.1 < fr["nonunitary_fraction"] < 0.3          # round 2: 1.5e8
 
@@ -88,12 +97,13 @@ def test_bench_line_of_several_ranks_on_one_gpu(world, tmp_path):
     assert res.returncode != 0 and "ncclCommInitRank" in d["rccl_error"]         # two ranks on one device: RCCL says no, the line says so
     assert d["n_gpus"] == world and d["device_gather"] == "hipIpc" and d["rccl_nranks"] == [world] * world
     assert d["host_segment"]["error"] is None and d["host_segment"]["bytes"] >= 256 * 512 * 40 * 12 * 8
+    assert d["host_segment"]["registered_ranks"] == world                       # ABI 5: every rank's mapping registered: DMA straight into it
     n = d["config"]["evals_per_step_per_gpu"]
     assert d["value"] == pytest.approx(world * n / (d["ms_per_step"] * 1e-3), rel=1e-6)   # the whole job: every rank's evaluations
     for key, npts, per in (("c4_scan_ref", 64, 2048 * 40 * 9 * 8), ("c5_scan_ref", 256, 512 * 40 * 12 * 8)):
         s = d[key]
         assert "error" not in s and s["ranks"] == world and s["gather"].startswith("shared host segment")
-        assert s["d2h_links"] == world and s["gather_bytes"] == 0
+        assert s["d2h_links"] == world and s["gather_bytes"] == 0 and "registered by every rank" in s["destination"]
         from golemflavor_amd import dist as gdist
         assert s["d2h_bytes_per_rank"] == [len(gdist.shard(npts, r, world)) * per for r in range(world)]
         assert s["d2h_bytes"] == npts * per == s["chain_bytes_to_host"]        # the result, once: summed over the ranks' links
