@@ -1340,8 +1340,10 @@ struct HostSink {
     int rc = GF_OK;
     std::chrono::steady_clock::time_point last_event;   // when the newest consumed block was seen complete
     // where the host thread's time went (diagnostics: gf_internal_run_to_host_times): [0] total / [1] longest call issuing a block's
-    // copy, [2] total / [3] longest wait for a block to complete, [4] blocks, [5] total / [6] longest enqueue of a block of steps
+    // copy, [2] total / [3] longest wait for a block to complete, [4] blocks, [5] total / [6] longest enqueue of a block of steps,
+    // [7] from the call's entry to the first block's mark (chain buffer, graph capture, the launch-shape probe)
     double t[8] = {};
+    std::chrono::steady_clock::time_point t_entry;
 };
 double g_last_run_to_host_times[8] = {};
 
@@ -1668,6 +1670,7 @@ hipError_t flight_admit(gf_sampler* s)
 hipError_t flight_mark(gf_sampler* s, hipStream_t st, int64_t nstored)
 {
     const int slot = (int)(s->flight_enq % gf_sampler::FLIGHT);
+    if (s->sink && s->sink->t[7] == 0.0) s->sink->t[7] = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->sink->t_entry).count();
     hipEvent_t& e = s->flight_ev[slot];
     if (!e) { const hipError_t ec = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (ec != hipSuccess) { e = nullptr; return ec; } }
     const hipError_t er = hipEventRecord(e, st);
@@ -1998,7 +2001,7 @@ int gf_sampler_run_to_host(gf_sampler* s, int64_t nsteps, int thin, double* chai
     HostSink sink;
     sink.chain = chain; sink.lnp = lnprob_chain; sink.total = s->nstored + (nsteps + thin - 1) / thin;
     sink.copy_stream = copy_stream; sink.device = device;
-    sink.last_event = std::chrono::steady_clock::now();
+    sink.last_event = sink.t_entry = std::chrono::steady_clock::now();
     if (gf_internal_env("GF_RUN_TO_HOST_NO_PIPE", 0) == nullptr) {       // diagnostics / A-B: else every block is a read-back of its own
         rc = gf_internal_d2h_pipe_open(device, copy_stream, &sink.pipe);
         if (rc != GF_OK) { gf_internal_return_copy_stream(device, copy_stream); return rc; }

@@ -172,6 +172,7 @@ GFX_HD inline dd dd_horner(dd c, dd t, dd k)
 
 GFX_HD inline dd dd_div(dd a, dd b)
 {
+#if defined(GFX87_ROUND64_R3)
     const double q1 = a.hi / b.hi;
     dd r = dd_sub(a, dd_mul_d(b, q1));
     const double q2 = r.hi / b.hi;
@@ -179,6 +180,23 @@ GFX_HD inline dd dd_div(dd a, dd b)
     const double q3 = r.hi / b.hi;
     dd q = dd_norm(q1, q2);
     return dd_add(q, dd_from(q3));
+#else
+    // Round 4: ONE fp64 division (the reciprocal of the divisor's head) instead of three, and the remainder a - q1 b formed directly --
+    // the heads' difference is exact (q1 b.hi is within an ulp of a.hi), the rest is of relative size 2^-52 and needs fp64 only.
+    // q1 + q2 + q3 is the quotient to ~2^-104, as before; ~45 operations instead of ~130.
+    const double r0 = 1.0 / b.hi;
+    const double q1 = a.hi * r0;
+    double p, e;
+    two_prod(q1, b.hi, p, e);
+    double r = (((a.hi - p) - e) + a.lo) - q1 * b.lo;              // a - q1 b
+    const double q2 = r * r0;
+    two_prod(q2, b.hi, p, e);
+    r = ((r - p) - e) - q2 * b.lo;                                 // ... - q2 b
+    const double q3 = r * r0;
+    double s, t;
+    quick_two_sum(q1, q2, s, t);
+    return dd_norm(s, t + q3);
+#endif
 }
 GFX_HD inline dd dd_div_d(dd a, double b)
 {
@@ -195,9 +213,15 @@ GFX_HD inline dd dd_sqrt(dd a)
     const double s0 = sqrt(a.hi);
     double p, e;
     two_prod(s0, s0, p, e);
-    const dd d = dd_sub(a, dd_norm(p, e));
     dd r;
+#if defined(GFX87_ROUND64_R3)
+    const dd d = dd_sub(a, dd_norm(p, e));
     two_sum(s0, d.hi / (2.0 * s0), r.hi, r.lo);
+#else
+    // a - s0^2: the heads' difference is exact (s0^2 is within an ulp of a.hi); the correction is below an ulp of s0
+    const double d = ((a.hi - p) - e) + a.lo;
+    quick_two_sum(s0, d / (2.0 * s0), r.hi, r.lo);
+#endif
     return r;
 }
 
@@ -464,7 +488,16 @@ GFX_HD inline void x_sincos(x87 a, x87& s, x87& c)
 GFX_HD inline x87 x_hypot(x87 a, x87 b)
 {
     const dd da = as_dd(a), db = as_dd(b);
+#if defined(GFX87_ROUND64_R3)
     return round64(dd_sqrt(dd_add(dd_mul(da, da), dd_mul(db, db))));
+#else
+    // the two squares are non-negative: their sum cancels nothing, the tails go in plain fp64 (11 operations instead of dd_add's 20)
+    const dd p = dd_mul(da, da), q = dd_mul(db, db);
+    double s, e;
+    two_sum(p.hi, q.hi, s, e);
+    e += p.lo + q.lo;
+    return round64(dd_sqrt(dd_norm(s, e)));
+#endif
 }
 
 // 1/2, 1/3, 1/9, 1/54 rounded to a 64-bit significand: what fr.py:205-209's `1./2`, `/ 3.`, `(1./9)`, `(1./54)` are in np.float128

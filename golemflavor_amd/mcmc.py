@@ -380,7 +380,7 @@ class DeviceEnsembleSampler:
         if fn(out) != 0:
             return None
         return {"copy_issue_s": round(out[0], 4), "copy_issue_max_s": round(out[1], 4), "block_wait_s": round(out[2], 4), "block_wait_max_s": round(out[3], 4),
-                "blocks": int(out[4]), "launch_s": round(out[5], 4), "launch_max_s": round(out[6], 4)}
+                "blocks": int(out[4]), "launch_s": round(out[5], 4), "launch_max_s": round(out[6], 4), "before_first_block_s": round(out[7], 4)}
 
     def undecided_census(self):
         st = self.chain_stats()

@@ -108,6 +108,11 @@ uint64_t x87t_digest(uint64_t seed, int64_t n, int64_t* wrong)
         const x87 r0 = x_add(xa, xb), r1 = x_sub(xa, xb), r2 = x_mul(xa, xb);
         h = fold(fold(fold(h, r0), r1), r2);
         *wrong += !same(to_ld(r0), a + b) + !same(to_ld(r1), a - b) + !same(to_ld(r2), a * b);
+        if (b != 0.0L) {                                                     // round 4 also shortened / and sqrt (hypot: faithful in libm, so digest only)
+            const x87 r3 = x_div(xa, xb), r4 = x_sqrt(x_abs(xa)), r5 = x_hypot(xa, xb);
+            h = fold(fold(fold(h, r3), r4), r5);
+            *wrong += !same(to_ld(r3), a / b) + !same(to_ld(r4), sqrtl(fabsl(a)));
+        }
     }
     return h;
 }
