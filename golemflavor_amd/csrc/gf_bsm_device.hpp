@@ -28,7 +28,8 @@ constexpr int TEX_NONE = 4;
 constexpr double UNI_EST_SCALE = 2048.0;
 constexpr double UNI_THRESHOLD = 1e-7 * UNI_EST_SCALE;    // estimate-only verdict
 // doubles of LDS a group of LPW lanes sharing one walker needs: [nb][3] compositions + 3 unitarity accumulators per lane
-#define GF_FGRP_DOUBLES(nb, lpw) (3 * (nb) + 3 * (lpw))
+#define GF_FGRP_PER_BIN 2                              // (f_e, f_mu) of a bin; the third follows from the unit sum
+#define GF_FGRP_DOUBLES(nb, lpw) (GF_FGRP_PER_BIN * (nb) + 3 * (lpw))
 
 struct UniAcc {
     double est_max;             // largest estimate over the bins tier 1 did not clear
@@ -457,7 +458,7 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         const double f0 = fma(p[0][1], dw1, fma(p[0][0], dw0, w2));
         const double f1 = fma(p[1][1], dw1, fma(p[1][0], dw0, w2));
         if (LPW > 1) {
-            fgrp[3 * k] = f0; fgrp[3 * k + 1] = f1;
+            fgrp[GF_FGRP_PER_BIN * k] = f0; fgrp[GF_FGRP_PER_BIN * k + 1] = f1;
         } else {
             const double wk = tb->weight[k];
             a0 = fma(f0, wk, a0); a1 = fma(f1, wk, a1);                         // fr.py:454
@@ -480,9 +481,9 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
     }
     if (LPW > 1) {
         if (UNI_MODE == UNI_INLINE) {
-            fgrp[3 * nb + sub] = acc.est_max;
-            fgrp[3 * nb + LPW + sub] = acc.clear_max;
-            fgrp[3 * nb + 2 * LPW + sub] = __longlong_as_double((long long)acc.amb);
+            fgrp[GF_FGRP_PER_BIN * nb + sub] = acc.est_max;
+            fgrp[GF_FGRP_PER_BIN * nb + LPW + sub] = acc.clear_max;
+            fgrp[GF_FGRP_PER_BIN * nb + 2 * LPW + sub] = __longlong_as_double((long long)acc.amb);
         }
         // the lanes of a group sit in one wave: its LDS operations retire in order, the fence keeps the compiler honest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -490,14 +491,14 @@ __device__ __forceinline__ void flux_average(const GfCommon& c, const GfBsm* __r
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int k = 0; k < nb; ++k) {
             const double wk = tb->weight[k];
-            a0 = fma(fgrp[3 * k], wk, a0); a1 = fma(fgrp[3 * k + 1], wk, a1);
+            a0 = fma(fgrp[GF_FGRP_PER_BIN * k], wk, a0); a1 = fma(fgrp[GF_FGRP_PER_BIN * k + 1], wk, a1);
         }
         if (UNI_MODE == UNI_INLINE) {
 #pragma unroll
             for (int j = 0; j < LPW; ++j) {
-                acc.est_max = fmax(acc.est_max, fgrp[3 * nb + j]);
-                acc.clear_max = fmax(acc.clear_max, fgrp[3 * nb + LPW + j]);
-                acc.amb |= (unsigned long long)__double_as_longlong(fgrp[3 * nb + 2 * LPW + j]);
+                acc.est_max = fmax(acc.est_max, fgrp[GF_FGRP_PER_BIN * nb + j]);
+                acc.clear_max = fmax(acc.clear_max, fgrp[GF_FGRP_PER_BIN * nb + LPW + j]);
+                acc.amb |= (unsigned long long)__double_as_longlong(fgrp[GF_FGRP_PER_BIN * nb + 2 * LPW + j]);
             }
         }
     }

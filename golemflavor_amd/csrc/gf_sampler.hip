@@ -275,21 +275,36 @@ __global__ __launch_bounds__(GF_BLOCK, GF_STRETCH_WAVES) void k_stretch_multi(co
     stretch_body<NDIM, MODE, LPW>(s.commons[chain], s.tbs[chain], s.ptabs[chain], s, chain, k, k < s.nwalkers / 2, t % LPW);
 }
 
-// Lanes per walker for a BSM half-step of `walkers` proposals: the fewest of {1, 4, 16} that put at least
-// four waves on every SIMD (two resident at this kernel's register budget, two queued); small ensembles are
-// bound by one walker's critical path (nbins diagonalisations in a row), not by throughput.
+// Lanes per walker for a BSM half-step of `walkers` proposals, from {1, 2, 4, 16}.  Splitting a walker's bins over L lanes shortens
+// its critical path from nbins to nbins / L bin evaluations but repeats the per-walker prologue on every lane and multiplies the
+// waves: small ensembles (a latency: one walker's chain on a GPU that is mostly idle) want the widest split, large ones the
+// narrowest that still keeps more than one wave on a SIMD.  A cost model instead of a table (round 4; tools/c5_lpw_ab.py): a lane
+// runs P + ceil(nbins / L) B instructions (P ~ 2000: prologue + the tier-2 terms of the chains that need them, B ~ 400 per bin),
+// a SIMD with w resident waves gives each an issue slot every max(7, 4 w) cycles, and waves beyond what is resident (three per
+// SIMD by registers; two at L = 2, whose 128 group buffers per block take more LDS) queue for another round.  C5's half-step of
+// 65 536 proposals: L = 2 (one round of two waves per SIMD) -- measured 79 us per half-step against 84 at L = 4, 94 at L = 1,
+// 122 at L = 16; ensembles of a few thousand proposals keep 16.
 inline int lanes_per_walker(int mode, int64_t walkers, int nbins_max, int cus)
 {
     if (mode != MODE_BSM_GAUSS || nbins_max < 2) return 1;
     const char* force = gf_internal_env("GF_SAMPLER_LPW", 0);                 // diagnostics / A-B, read per run
-    if (force) { const int f = std::atoi(force); if (f == 1 || f == 4 || f == 16) return f; }
-    const int64_t want = (int64_t)cus * 4 * 4;
-    for (int lpw : {1, 4, 16}) {
+    if (force) { const int f = std::atoi(force); if (f == 1 || f == 2 || f == 4 || f == 16) return f; }
+    const int64_t simds = (int64_t)(cus > 0 ? cus : 256) * 4;
+    int best = 1;
+    double best_cost = 0.0;
+    for (int lpw : {1, 2, 4, 16}) {
         const size_t lds = (size_t)(GF_BLOCK / lpw) * GF_FGRP_DOUBLES(nbins_max, lpw) * sizeof(double);
-        if (lpw > 1 && lds > 40 * 1024) return lpw == 4 ? 1 : 4;      // group buffers no longer fit beside the tiles
-        if ((walkers * lpw + GF_WAVE - 1) / GF_WAVE >= want || lpw == 16) return lpw;
+        if (lpw > 1 && lds > 48 * 1024) continue;                            // group buffers no longer fit beside the tiles
+        const int64_t waves = (walkers * lpw + GF_WAVE - 1) / GF_WAVE;
+        const int64_t wmax = lpw == 2 ? 2 : 3;
+        const int64_t per_simd = (waves + simds - 1) / simds;
+        const int64_t w = per_simd < wmax ? per_simd : wmax;
+        const int64_t rounds = (waves + simds * wmax - 1) / (simds * wmax);
+        const double interval = 4.0 * (double)w > 7.0 ? 4.0 * (double)w : 7.0;
+        const double cost = (double)rounds * (2000.0 + 400.0 * (double)((nbins_max + lpw - 1) / lpw)) * interval;
+        if (lpw == 1 || cost < best_cost) { best = lpw; best_cost = cost; }
     }
-    return 1;
+    return best;
 }
 
 template <int NDIM, int MODE, int LPW>
@@ -1257,6 +1272,7 @@ hipError_t launch_stretch_n(const GfCommon& c, const GfBsm* tb, const double* pt
     case MODE_SM_GAUSS: return launch_stretch_nml<NDIM, MODE_SM_GAUSS, 1>(c, tb, ptab, a, st);
     default:
         switch (a.lpw) {
+        case 2: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 2>(c, tb, ptab, a, st);
         case 4: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 4>(c, tb, ptab, a, st);
         case 16: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 16>(c, tb, ptab, a, st);
         default: return launch_stretch_nml<NDIM, MODE_BSM_GAUSS, 1>(c, tb, ptab, a, st);

@@ -156,7 +156,7 @@ def test_stacked_grid_sampler_bsm_grid_points():
 
 
 def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
-    """Small BSM ensembles split a walker's energy bins over 4 or 16 lanes (critical path nbins -> nbins/LPW);
+    """BSM ensembles split a walker's energy bins over 2, 4 or 16 lanes (critical path nbins -> nbins/LPW);
     the in-order weighted sum makes the chain bitwise independent of that choice."""
     asimov, ps = Cf.fr_paramsets(6, (0.4444444444444444, 0.0))
     args = bsm_args(6, Texture.OET, (0., 1., 0.))
@@ -166,7 +166,7 @@ def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
     p0[:, :, 11] = rng.uniform(-52, -40, (3, 48))
     chains = {}
     monkeypatch.setenv("GF_SAMPLER_CHAIN", "0")                # the per-half-step grid kernels (ensembles this small take k_stretch_chain otherwise)
-    for lpw in ("1", "4", "16"):
+    for lpw in ("1", "2", "4", "16"):
         monkeypatch.setenv("GF_SAMPLER_LPW", lpw)
         s = mcmc_utils.DeviceEnsembleSampler(48, 12, f, nchains=3, seed=21)
         s.on_nonunitary = "-inf"
@@ -175,7 +175,7 @@ def test_bsm_sampler_lanes_per_walker_is_bitwise_neutral(monkeypatch):
         s.close()
     monkeypatch.delenv("GF_SAMPLER_LPW")
     monkeypatch.delenv("GF_SAMPLER_CHAIN")
-    for lpw in ("4", "16"):
+    for lpw in ("2", "4", "16"):
         for x, y in zip(chains["1"], chains[lpw]):
             assert np.array_equal(x, y, equal_nan=True), lpw
     assert np.isfinite(chains["1"][1]).mean() > 0.5 and 0.05 < chains["1"][2].mean() < 0.9

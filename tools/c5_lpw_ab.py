@@ -10,7 +10,7 @@ import bench  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 os.environ["GF_SAMPLER_CHAIN"] = "0"
 for rep in range(reps):
-    for lpw in ("", "1", "4", "16"):
+    for lpw in ("", "1", "2", "4", "16"):
         if lpw:
             os.environ["GF_SAMPLER_LPW"] = lpw
         else:
