@@ -1362,6 +1362,7 @@ struct HostSink {
     std::chrono::steady_clock::time_point t_entry;
 };
 double g_last_run_to_host_times[8] = {};
+double g_last_run_prologue[4] = {};             // the last gf_sampler_run: [0] growing the chain buffers, [1] capturing + instantiating the graph (seconds)
 
 // accessors implemented in gf_capi.hip (gf_model is private to it)
 extern "C" {
@@ -1715,6 +1716,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             while (cap < need) cap *= 2;
             double *nc = nullptr, *nl = nullptr;
             GFS_HIP(hipStreamSynchronize(st));
+            const auto t_grow = std::chrono::steady_clock::now();
+            struct Grow { std::chrono::steady_clock::time_point t0; ~Grow() { g_last_run_prologue[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } grow_{t_grow};
             GFS_HIP(hipMalloc((void**)&nc, sizeof(double) * nw * s->ndim * cap));
             {
                 hipError_t e_ = hipMalloc((void**)&nl, sizeof(double) * nw * cap);
@@ -1940,6 +1943,8 @@ int gf_sampler_run(gf_sampler* s, int64_t nsteps, int thin, int store)
             s->graph_has_chain != (store ? 1 : 0)) {
             if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }
             hipGraph_t g = nullptr;
+            const auto t_cap = std::chrono::steady_clock::now();
+            struct Cap { std::chrono::steady_clock::time_point t0; ~Cap() { g_last_run_prologue[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } cap_{t_cap};
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 e = steps(GRAPH_STEPS);
@@ -2066,6 +2071,12 @@ int gf_internal_run_to_host_times(double out[8])
 {
     if (!out) return GF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i) out[i] = g_last_run_to_host_times[i];
+    return GF_OK;
+}
+int gf_internal_run_prologue_times(double out[4])
+{
+    if (!out) return GF_ERR_INVALID_ARG;
+    for (int i = 0; i < 4; ++i) out[i] = g_last_run_prologue[i];
     return GF_OK;
 }
 

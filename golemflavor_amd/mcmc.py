@@ -379,7 +379,14 @@ class DeviceEnsembleSampler:
         fn.restype, fn.argtypes = self._C.c_int, [self._C.POINTER(self._C.c_double)]
         if fn(out) != 0:
             return None
-        return {"copy_issue_s": round(out[0], 4), "copy_issue_max_s": round(out[1], 4), "block_wait_s": round(out[2], 4), "block_wait_max_s": round(out[3], 4),
+        extra = {}
+        fn2 = getattr(self._L, "gf_internal_run_prologue_times", None)
+        if fn2 is not None:
+            pr = (self._C.c_double * 4)()
+            fn2.restype, fn2.argtypes = self._C.c_int, [self._C.POINTER(self._C.c_double)]
+            if fn2(pr) == 0:
+                extra = {"grow_chain_buffers_s": round(pr[0], 4), "graph_capture_s": round(pr[1], 4)}
+        return {**extra, "copy_issue_s": round(out[0], 4), "copy_issue_max_s": round(out[1], 4), "block_wait_s": round(out[2], 4), "block_wait_max_s": round(out[3], 4),
                 "blocks": int(out[4]), "launch_s": round(out[5], 4), "launch_max_s": round(out[6], 4), "before_first_block_s": round(out[7], 4)}
 
     def undecided_census(self):

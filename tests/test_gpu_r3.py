@@ -257,3 +257,48 @@ def test_read_backs_into_a_registered_arena_equal_those_through_the_ring(golden)
     finally:
         arena.close()
     assert not arena.registered and arena.take((1,)) is None
+
+
+def test_large_device_buffers_are_cached_not_freed():
+    """gf_devcache.h (round 4): a device buffer of 64 MB or more goes to the library's free list when it is freed and is handed out
+    again for the next request it fits -- the driver wipes freed memory with the DMA engine, which halved every read-back that
+    followed a free.  Small buffers are freed as before; `gf_device_trim` hands the cached ones back."""
+    import ctypes as C
+    L = _lib.lib()
+    L.gf_devcache_stats.restype = None
+    L.gf_devcache_stats.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong)]
+
+    def stats():
+        idle, live, reuses = C.c_size_t(), C.c_size_t(), C.c_ulonglong()
+        L.gf_devcache_stats(0, C.byref(idle), C.byref(live), C.byref(reuses))
+        return idle.value, live.value, reuses.value
+
+    _lib.device_trim(0)
+    idle0, live0, reuse0 = stats()
+    assert idle0 == 0
+    p = C.c_void_p()
+    _lib.check(L.gf_device_malloc(0, 200 << 20, C.byref(p)), "gf_device_malloc")
+    first = p.value
+    assert stats()[1] == live0 + (200 << 20)
+    _lib.check(L.gf_device_release(0, p), "gf_device_release")
+    assert stats()[0] == 200 << 20 and stats()[1] == live0                       # idle in the cache, not freed
+    q = C.c_void_p()
+    _lib.check(L.gf_device_malloc(0, 180 << 20, C.byref(q)), "gf_device_malloc")    # fits (within +25 %): the same block
+    assert q.value == first and stats()[2] == reuse0 + 1 and stats()[0] == 0
+    r = C.c_void_p()
+    _lib.check(L.gf_device_malloc(0, 100 << 20, C.byref(r)), "gf_device_malloc")    # nothing idle: a new block
+    assert r.value != first
+    _lib.check(L.gf_device_release(0, q), "gf_device_release")
+    _lib.check(L.gf_device_release(0, r), "gf_device_release")
+    s = C.c_void_p()
+    _lib.check(L.gf_device_malloc(0, 110 << 20, C.byref(s)), "gf_device_malloc")    # 200 MB is more than 25 % too large: the 100 MB block is too small -> new
+    assert s.value not in (first, r.value)
+    _lib.check(L.gf_device_release(0, s), "gf_device_release")
+    small = C.c_void_p()
+    _lib.check(L.gf_device_malloc(0, 1 << 20, C.byref(small)), "gf_device_malloc")  # below the threshold: not tracked
+    live = stats()[1]
+    _lib.check(L.gf_device_release(0, small), "gf_device_release")
+    assert stats()[1] == live
+    assert stats()[0] == (200 << 20) + (100 << 20) + (110 << 20)
+    assert _lib.device_trim(0) >= (200 << 20) + (100 << 20) + (110 << 20)
+    assert stats()[0] == 0
