@@ -539,3 +539,20 @@ def test_node_identity_is_the_boot_id():
     boot = open("/proc/sys/kernel/random/boot_id").read().strip().encode()
     assert ident == boot and len(ident) == 36
     assert gdist.same_node(gdist.LocalBackend())
+
+
+def test_host_segment_registration_is_local_and_survives_having_no_gpu():
+    """`HostSegment.register` (ABI 5) is not a collective: a rank whose registration fails -- here: no GPU -- says so and keeps the
+    pinned ring; the segment works as before, and `close` after a failed registration is quiet."""
+    from golemflavor_amd import dist as gdist
+    seg = gdist.HostSegment(gdist.LocalBackend(), 1 << 20)
+    assert seg.error is None
+    ok, secs = seg.register()
+    a = seg.array((1 << 17,))
+    a[:] = 3.0
+    assert float(a.sum()) == 3.0 * (1 << 17)
+    if not ok:
+        assert seg.register_error and secs >= 0.0
+    assert seg.register() == (ok, 0.0)                      # asked once
+    del a
+    seg.close()
