@@ -1466,20 +1466,21 @@ struct gf_d2h_pipe {
     bool direct_pending = false;            // blocks went straight into a registered destination: _close waits for the stream
 };
 
-int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out)
+// The ring (eight pinned 16 MB slots, allocated once per device) and the consumer thread are set up when the first chunk needs them:
+// a pipe whose blocks all go straight into a registered destination never touches either (and a run does not start with 128 MB of
+// hipHostMalloc, 30 ms when it is the process's first and now and then several times that).
+static int pipe_start(gf_d2h_pipe* p)
 {
-    if (device < 0 || device >= POOL_MAX_DEVICES || !out) return GF_ERR_INVALID_ARG;
-    *out = nullptr;
-    gf_d2h_pipe* p = new (std::nothrow) gf_d2h_pipe();
-    if (!p) return GF_ERR_ALLOC;
-    p->device = device; p->st = (hipStream_t)stream; p->ring = &g_d2h[device];
-    p->ring->mu.lock();                                   // one large read-back at a time per device; released by _close
+    if (p->ring) return GF_OK;
+    D2HRing* ring = &g_d2h[p->device];
+    ring->mu.lock();                                      // one large read-back at a time per device; released by _close
     for (int k = 0; k < D2H_SLOTS; ++k) {
         hipError_t e = hipSuccess;
-        if (!p->ring->slot[k]) e = hipHostMalloc(&p->ring->slot[k], D2H_SLOT, hipHostMallocDefault);
-        if (e == hipSuccess && !p->ring->ev[k]) e = hipEventCreateWithFlags(&p->ring->ev[k], hipEventDisableTiming);
-        if (e != hipSuccess) { p->ring->mu.unlock(); delete p; return hip_fail(e, "gf_internal_d2h_pipe_open"); }
+        if (!ring->slot[k]) e = hipHostMalloc(&ring->slot[k], D2H_SLOT, hipHostMallocDefault);
+        if (e == hipSuccess && !ring->ev[k]) e = hipEventCreateWithFlags(&ring->ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) { ring->mu.unlock(); return hip_fail(e, "gf_internal_d2h_pipe: ring"); }
     }
+    p->ring = ring;
     p->consumer = std::thread([p]() {
         for (size_t c = 0;; ++c) {
             while (p->issued.load(std::memory_order_acquire) <= c) {
@@ -1497,6 +1498,16 @@ int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out)
             p->drained.store(c + 1, std::memory_order_release);
         }
     });
+    return GF_OK;
+}
+
+int gf_internal_d2h_pipe_open(int device, void* stream, gf_d2h_pipe** out)
+{
+    if (device < 0 || device >= POOL_MAX_DEVICES || !out) return GF_ERR_INVALID_ARG;
+    *out = nullptr;
+    gf_d2h_pipe* p = new (std::nothrow) gf_d2h_pipe();
+    if (!p) return GF_ERR_ALLOC;
+    p->device = device; p->st = (hipStream_t)stream; p->ring = nullptr;
     *out = p;
     return GF_OK;
 }
@@ -1516,6 +1527,10 @@ int gf_internal_d2h_pipe_rows(gf_d2h_pipe* p, void* dst_host, size_t dpitch, con
         if (e != hipSuccess) { p->failed.store(1); return hip_fail(e, "gf_internal_d2h_pipe_rows"); }
         p->direct_pending = true;
         return GF_OK;
+    }
+    {
+        const int rc = pipe_start(p);
+        if (rc != GF_OK) { p->failed.store(1); return rc; }
     }
     auto issue = [&](char* d, size_t dp, const char* sp, size_t spi, size_t w, size_t nr) {
         const size_t c = p->issued.load(std::memory_order_relaxed);
@@ -1548,7 +1563,7 @@ int gf_internal_d2h_pipe_close(gf_d2h_pipe* p)
     if (p->consumer.joinable()) p->consumer.join();
     if (p->direct_pending && hipStreamSynchronize(p->st) != hipSuccess) p->failed.store(1);
     const int bad = p->failed.load();
-    p->ring->mu.unlock();
+    if (p->ring) p->ring->mu.unlock();
     delete p;
     if (bad) { std::snprintf(g_err, sizeof(g_err), "gf_internal_d2h_pipe: a copy or an event wait failed"); return GF_ERR_HIP; }
     return GF_OK;
