@@ -269,22 +269,22 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     const cx87 h10h02 = g.ex[0], h21h10 = g.ex[1], h12h20 = g.ex[2];
     if (tick) tick[1] = clock64();
     const cx87 a = c_neg(tr);                                                           // fr.py:204
-    const cx87 a2 = c_mul(tr, tr);                                                      // = a a, bit for bit: (-x)(-y) is x y
-    const cx87 b = c_scale(GFX_X87_HALF, c_sub(a2, tr2));                               // fr.py:205
+    const cx87 a2 = c_sqr(tr);                                                          // = a a, bit for bit: (-x)(-y) is x y; a square: gf_x87.hpp c_sqr
+    const cx87 b = c_times2(c_sub(a2, tr2), 0.5);                                       // fr.py:205 (halving is exact)
     const cx87 c = c_neg(det);                                                          // fr.py:206
     const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
     const cx87 R = c_scale(GFX_X87_54TH,
-                           c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
+                           c_add(c_sub(c_times2(c_mul(a, a2), 2.0), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
     // the two complex square roots of the bin, sqrt(Q^3) (fr.py:210) and sqrt(Q) (fr.py:212-214), in ONE pass: lanes 0 and 1 take
     // the first, lane 2 the second, and they meet in the exchange slot
-    const cx87 Q3 = c_mul(Q, c_mul(Q, Q));
+    const cx87 Q3 = c_mul(Q, c_sqr(Q));
     g.ex[r] = c_sqrt_pos(r == 2 ? Q : Q3);
     grp_sync();
     const cx87 sqQ3 = g.ex[0], sq = g.ex[2];
     grp_sync();
     const cx87 theta = c_acos_near_real(c_div(R, sqQ3));                                // fr.py:210
     if (tick) tick[2] = clock64();
-    const cx87 m2sq = c_scale(x_neg(two), sq);
+    const cx87 m2sq = c_times2(sq, -2.0);
     const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
     const x87 twopi = x_mul(two, pi);
@@ -292,18 +292,20 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     x87 are = theta.re;
     if (r == 1) are = x_sub(theta.re, twopi);
     if (r == 2) are = x_add(theta.re, twopi);
-    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(are, theta.im), three))), third_a);
+    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_scale(GFX_X87_THIRD, c_make(are, theta.im)))), third_a);
     if (tick) tick[3] = clock64();
     // eigenvector r (fr.py:216-236)
     const cx87 A = c_sub(c_mul(M[5], c_sub(M[0], E)), h10h02);
     const cx87 B = c_sub(c_mul(M[6], c_sub(M[4], E)), h21h10);
     const cx87 C = c_sub(c_mul(M[3], c_sub(M[8], E)), h12h20);
-    const cx87 AB = c_mul(A, B), AC = c_mul(A, C), BC = c_mul(B, C);
+    // B C and conj(B) C (fr.py:232) are made of the SAME four products: conj(B) = (Br, -Bi), and (-Bi) Ci = -(Bi Ci) exactly
+    const x87 brcr = x_mul(B.re, C.re), bici = x_mul(B.im, C.im), brci = x_mul(B.re, C.im), bicr = x_mul(B.im, C.re);
+    const cx87 AB = c_mul(A, B), AC = c_mul(A, C), BC = c_make(x_sub(brcr, bici), x_add(brci, bicr));
     const x87 ab = c_abs(AB), ac = c_abs(AC), bc = c_abs(BC);
     const x87 N = x_sqrt(x_add(x_add(x_mul(ab, ab), x_mul(ac, ac)), x_mul(bc, bc)));   // fr.py:228-230
     // fr.py:232-236: complex / real is x * (1 / d) in numpy (c_div_real): the reciprocal once for the three components
     const x87 rn = x_div(x_from(1.0), N);
-    const cx87 cbc = c_mul(c_conj(B), C);
+    const cx87 cbc = c_make(x_add(brcr, bici), x_sub(brci, bicr));                      // c_mul(c_conj(B), C)
     const cx87 x0 = c_make(x_mul(cbc.re, rn), x_mul(cbc.im, rn));
     const cx87 x1 = c_make(x_mul(AC.re, rn), x_mul(AC.im, rn));
     const cx87 x2 = c_make(x_mul(AB.re, rn), x_mul(AB.im, rn));
@@ -311,18 +313,22 @@ __device__ __forceinline__ double grp_bin_residual(const Grp& g, const cx87 hs[3
     grp_sync();                                                                         // every lane is done with H
     M[0 + r] = x0; M[3 + r] = x1; M[6 + r] = x2;                                        // column r of X
     grp_sync();
-    // f = |X X^+| (fr.py:489): lane 0 -> f00, f01; lane 1 -> f02, f11; lane 2 -> f12, f22
+    // f = |X X^+| (fr.py:489): lane r -> the diagonal entry f_rr first (all three lanes together: a sum of squares, its modulus
+    // itself -- gf_x87.hpp c_norm2), then one entry above the diagonal: lane 0 -> f01, lane 1 -> f02, lane 2 -> f12
     {
-        x87* exx = reinterpret_cast<x87*>(g.ex);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int idx = 2 * r + e;                                                  // 0..5 = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-            const int i = idx < 3 ? 0 : (idx < 5 ? 1 : 2);
-            const int j = idx < 3 ? idx : (idx < 5 ? idx - 2 : 2);
+        x87* exx = reinterpret_cast<x87*>(g.ex);                                        // 0..5 = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        {
+            x87 d = c_norm2(M[3 * r + 0]);
+            d = x_add(d, c_norm2(M[3 * r + 1]));
+            d = x_add(d, c_norm2(M[3 * r + 2]));
+            exx[r == 0 ? 0 : (r == 1 ? 3 : 5)] = d;
+        }
+        {
+            const int i = r == 2 ? 1 : 0, j = r == 0 ? 1 : 2;
             cx87 sacc = c_mul(M[3 * i + 0], c_conj(M[3 * j + 0]));
             sacc = c_add(sacc, c_mul(M[3 * i + 1], c_conj(M[3 * j + 1])));
             sacc = c_add(sacc, c_mul(M[3 * i + 2], c_conj(M[3 * j + 2])));
-            exx[idx] = c_abs(sacc);
+            exx[r == 0 ? 1 : (r == 1 ? 2 : 4)] = c_abs(sacc);
         }
     }
     grp_sync();
@@ -498,13 +504,13 @@ __device__ __forceinline__ double g9_bin_residual(const Grp9& g, cx87 hs, cx87 h
     }
     grp_sync();
     const cx87 a = c_neg(tr);                                                           // fr.py:204
-    const cx87 a2 = c_mul(tr, tr);                                                      // = a a, bit for bit
-    const cx87 b = c_scale(GFX_X87_HALF, c_sub(a2, tr2));                               // fr.py:205
+    const cx87 a2 = c_sqr(tr);                                                          // = a a, bit for bit; a square: gf_x87.hpp c_sqr
+    const cx87 b = c_times2(c_sub(a2, tr2), 0.5);                                       // fr.py:205 (halving is exact)
     const cx87 cc = c_neg(det);                                                         // fr.py:206
     const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
     const cx87 R = c_scale(GFX_X87_54TH,
-                           c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, cc)));   // fr.py:209
-    const cx87 Q3 = c_mul(Q, c_mul(Q, Q));
+                           c_add(c_sub(c_times2(c_mul(a, a2), 2.0), c_mul(c_scale(nine, a), b)), c_scale(n27, cc)));   // fr.py:209
+    const cx87 Q3 = c_mul(Q, c_sqr(Q));
     {
         cx87* ex = reinterpret_cast<cx87*>(sm);
         const cx87 root = c_sqrt_pos(r == 2 ? Q : Q3);                                   // both square roots of the bin in one pass
@@ -515,7 +521,7 @@ __device__ __forceinline__ double g9_bin_residual(const Grp9& g, cx87 hs, cx87 h
     { const cx87* ex = reinterpret_cast<const cx87*>(sm); sqQ3 = ex[0]; sq = ex[2]; }
     grp_sync();
     const cx87 theta = c_acos_near_real(c_div(R, sqQ3));                                // fr.py:210
-    const cx87 m2sq = c_scale(x_neg(two), sq);
+    const cx87 m2sq = c_times2(sq, -2.0);
     const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};
     const x87 twopi = x_mul(two, pi);
@@ -523,7 +529,7 @@ __device__ __forceinline__ double g9_bin_residual(const Grp9& g, cx87 hs, cx87 h
     x87 are = theta.re;
     if (r == 1) are = x_sub(theta.re, twopi);
     if (r == 2) are = x_add(theta.re, twopi);
-    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_div_real(c_make(are, theta.im), three))), third_a);
+    const cx87 E = c_sub(c_mul(m2sq, c_cos_near_real(c_scale(GFX_X87_THIRD, c_make(are, theta.im)))), third_a);
     {
         const cx87 mi = c == 0 ? M[5] : (c == 1 ? M[6] : M[3]);
         const cx87 mjj = c == 0 ? M[0] : (c == 1 ? M[4] : M[8]);

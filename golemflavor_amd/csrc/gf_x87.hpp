@@ -133,6 +133,18 @@ GFX_HD inline dd dd_add(dd a, dd b)
     return dd_norm(s1, e1);
 }
 GFX_HD inline dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
+// a double plus a double-double: the heads exactly, the tail in fp64 (11 operations instead of dd_add's 20; where the sum cancels,
+// the heads' sum is exact and small and the tail is added to it exactly)
+GFX_HD inline dd dd_add_d(double a, dd b)
+{
+#if defined(GFX87_ROUND64_R3)
+    return dd_add(dd_from(a), b);
+#endif
+    double s, e;
+    two_sum(a, b.hi, s, e);
+    e += b.lo;
+    return dd_norm(s, e);
+}
 
 GFX_HD inline dd dd_mul(dd a, dd b)
 {
@@ -424,8 +436,7 @@ GFX_HD inline dd dd_pi() { dd r = {2.0 * GFX_PIO2_1, 2.0 * GFX_PIO2_2}; return r
 // sqrt((1 - a)(1 + a)) for 0 <= a <= 1
 GFX_HD inline dd dd_cofunc(dd a)
 {
-    const dd one = dd_from(1.0);
-    return dd_sqrt(dd_mul(dd_sub(one, a), dd_add(one, a)));
+    return dd_sqrt(dd_mul(dd_add_d(1.0, dd_neg(a)), dd_add_d(1.0, a)));
 }
 
 GFX_HD inline dd dd_asin(dd s)      // s in [-1, 1]
@@ -518,6 +529,21 @@ GFX_HD GFX_CMUL cx87 c_mul(cx87 a, cx87 b)
 {
     return c_make(x_sub(x_mul(a.re, b.re), x_mul(a.im, b.im)), x_add(x_mul(a.re, b.im), x_mul(a.im, b.re)));
 }
+// Three places where the reference's operations have an EXACT outcome that needs no emulated arithmetic (round 4; the values are the
+// chain's, bit for bit -- the three-lane chain uses them; the serial chain below (the statement the host build checks against the x87
+// unit) and the nine-lane chain keep the long way unless GFX87_SHORT_A / _B / _C are defined, and the tests compare both ways):
+//   z * z: numpy's (ac - bd, ad + bc) with c = a, d = b -- the two cross products are the same number and their sum is its double;
+//   2 * z, -2 * z, z / 2 (fr.py:205's `1./2`): a doubling or halving is exact in any binary format;
+//   z * conj(z): (a a - b (-b), a (-b) + b a) = (RN(a^2) + RN(b^2), -p + p = 0), so the diagonal of X X^+ is a sum of squares with an
+//   imaginary part of exactly zero, and its modulus hypotl(s, 0) is s.
+GFX_HD inline cx87 c_sqr(cx87 z)
+{
+    const x87 p = x_mul(z.re, z.im);
+    return c_make(x_sub(x_mul(z.re, z.re), x_mul(z.im, z.im)), x_scale2(p, 2.0));
+}
+GFX_HD inline cx87 c_times2(cx87 z, double two) { return c_make(x_scale2(z.re, two), x_scale2(z.im, two)); }       // two = 2.0, -2.0 or 0.5
+GFX_HD inline x87 c_norm2(cx87 z) { return x_add(x_mul(z.re, z.re), x_mul(z.im, z.im)); }                        // Re(z conj z); Im is exactly 0
+
 // real * complex: numpy promotes the real to (r, 0); the products with the zero are exact, so this is a scaling
 GFX_HD GFX_CADD cx87 c_scale(x87 r, cx87 a) { return c_make(x_mul(r, a.re), x_mul(r, a.im)); }
 // numpy's complex division (Smith)
@@ -559,10 +585,10 @@ GFX_HD inline cx87 c_acos_near_real(cx87 z)
     const dd x = as_dd(z.re);
     const dd ax = x.hi < 0.0 ? dd_neg(x) : x;
     const dd one = dd_from(1.0);
-    const dd om = dd_sub(one, ax);                                    // 1 - |x|
+    const dd om = dd_add_d(1.0, dd_neg(ax));                          // 1 - |x|
     if (om.hi > 0.0) {
         const x87 re = round64(dd_acos(x));
-        const dd den = dd_sqrt(dd_mul(om, dd_add(one, ax)));
+        const dd den = dd_sqrt(dd_mul(om, dd_add_d(1.0, ax)));
         const x87 im = x_neg(round64(dd_div(as_dd(z.im), den)));
         return c_make(re, im);
     }
@@ -649,18 +675,39 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
         tr2 = c_add(c_add(d[0], d[1]), d[2]);
     }
     const cx87 a = c_neg(tr);                                                           // fr.py:204
+#if defined(GFX87_SHORT_A)
+    const cx87 b = c_times2(c_sub(c_sqr(tr), tr2), 0.5);                                // fr.py:205 (halving is exact)
+#else
     const cx87 b = c_scale(GFX_X87_HALF, c_sub(c_mul(tr, tr), tr2));                    // fr.py:205
+#endif
     const cx87 det = c_add(c_sub(c_mul(h[0][0], c_sub(c_mul(h[1][1], h[2][2]), c_mul(h[2][1], h[1][2]))),
                                  c_mul(h[1][0], c_sub(c_mul(h[0][1], h[2][2]), c_mul(h[2][1], h[0][2])))),
                            c_mul(h[2][0], c_sub(c_mul(h[0][1], h[1][2]), c_mul(h[1][1], h[0][2]))));   // fr.py:77-79
     const cx87 c = c_neg(det);                                                          // fr.py:206
+#if defined(GFX87_SHORT_A)
+    const cx87 a2 = c_sqr(a);
+#else
     const cx87 a2 = c_mul(a, a);
+#endif
     const cx87 Q = c_scale(GFX_X87_NINTH, c_sub(a2, c_scale(three, b)));                // fr.py:208
+#if defined(GFX87_SHORT_B)
+    const cx87 R = c_scale(GFX_X87_54TH,
+                           c_add(c_sub(c_times2(c_mul(a, a2), 2.0), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
+#else
     const cx87 R = c_scale(GFX_X87_54TH,
                            c_add(c_sub(c_scale(two, c_mul(a, a2)), c_mul(c_scale(nine, a), b)), c_scale(n27, c)));   // fr.py:209
+#endif
+#if defined(GFX87_SHORT_A)
+    const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_sqr(Q)))));      // fr.py:210
+#else
     const cx87 theta = c_acos_near_real(c_div(R, c_sqrt_pos(c_mul(Q, c_mul(Q, Q)))));   // fr.py:210
+#endif
     const cx87 sq = c_sqrt_pos(Q);
+#if defined(GFX87_SHORT_B)
+    const cx87 m2sq = c_times2(sq, -2.0);
+#else
     const cx87 m2sq = c_scale(x_neg(two), sq);
+#endif
     const cx87 third_a = c_scale(GFX_X87_THIRD, a);
     const x87 pi = {3.141592653589793, 1.22514845490862e-16};                           // np.arccos(np.float128(-1)), fr.py:24
     const x87 twopi = x_mul(two, pi);
@@ -688,6 +735,15 @@ GFX_HD inline double cardano_residual(const cx87 h[3][3])
     for (int i = 0; i < 3; ++i)
         GFX_ROLLED
         for (int j = i; j < 3; ++j) {
+#if defined(GFX87_SHORT_C)
+            if (i == j) {
+                x87 d = c_norm2(x[i][0]);
+                d = x_add(d, c_norm2(x[i][1]));
+                d = x_add(d, c_norm2(x[i][2]));
+                f[i][j] = d;
+                continue;
+            }
+#endif
             cx87 s = c_mul(x[i][0], c_conj(x[j][0]));
             s = c_add(s, c_mul(x[i][1], c_conj(x[j][1])));
             s = c_add(s, c_mul(x[i][2], c_conj(x[j][2])));

@@ -93,6 +93,34 @@ def test_round4_chain_residuals_equal_round3s(golden, x87lib, tmp_path):
     assert n == 3200 and big > 1000
 
 
+def test_exact_shortcuts_of_the_three_lane_chain(golden, x87lib, tmp_path):
+    """Round 4: the three-lane chain skips emulated arithmetic where the reference's own operations have an exact outcome -- z * z
+    (the two cross products are one number, their sum its double), 2 z and -2 z, and z conj(z) (imaginary part exactly zero, so
+    the diagonal of |X X^+| is a sum of squares and its own modulus).  The serial chain with the same shortcuts switched on
+    (-DGFX87_SHORT_A/B/C) gives the same residual, bit for bit, on 300 G17 rows x 20 bins; on the device the three-lane chain is
+    compared with the serial one (tests/test_gpu_unitarity_r3.py)."""
+    out = str(tmp_path / "libx87host_short.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-fPIC", "-shared", "-ffp-contract=off", "-DGFX87_SHORT_A", "-DGFX87_SHORT_B",
+                           "-DGFX87_SHORT_C", "-o", out, os.path.join(ROOT, "tests", "x87", "x87_host.cpp")])
+    short = C.CDLL(out)
+    short.x87t_bin_residual.restype = C.c_double
+    short.x87t_bin_residual.argtypes = x87lib.x87t_bin_residual.argtypes
+    rows = golden["g17_rows"]
+    centres = np.sqrt(BIN_EDGES[:-1] * BIN_EDGES[1:])
+    rng = np.random.default_rng(5)
+    n = 0
+    for i in rng.permutation(len(rows))[:300]:
+        r = rows[i]
+        dim, tex, th = int(r[0]), int(r[1]), r[2:]
+        sc2 = math.pow(10., th[6])
+        for e in centres:
+            a = x87lib.x87t_bin_residual(_arr(th[:4]), _arr(TEX[tex]), th[4], th[5], sc2, e, dim, None, None)
+            b = short.x87t_bin_residual(_arr(th[:4]), _arr(TEX[tex]), th[4], th[5], sc2, e, dim, None, None)
+            assert a == b or (a != a and b != b), (i, e, a, b)
+            n += 1
+    assert n == 6000
+
+
 def test_functions_are_correctly_rounded_neighbours_of_libm(x87lib):
     """asinl, acosl, sinl, cosl, hypotl: the emulation evaluates to ~2^-100 and rounds; glibc / the x87 microcode are
     faithful (< 1 ulp).  They must never differ by more than one unit in the last place, and agree in most calls."""
