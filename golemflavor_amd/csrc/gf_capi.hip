@@ -238,12 +238,11 @@ hipError_t pool_stream(int device, hipStream_t* stream)
 }
 
 // A stream for a read-back that is to run BESIDE kernels of another stream.  The runtime multiplexes its streams onto a handful of
-// hardware queues (four by default), round-robin: a copy stream that lands on the compute stream's queue has its copies -- their
-// barrier packets -- queued BEHIND every kernel already enqueued there, and "post-process group by group while the finished groups cross
-// PCIe" silently becomes "post-process everything, then copy" (measured: C4's 9.4 GB of rows 0.18 s when the two streams sat on
-// different queues, 0.31 s = the sum of both when they shared one; which of the two a run got depended on how many streams the process
-// had created before: profiles/r04/host_register.txt).  Streams of another PRIORITY get hardware queues of their own, so the copy
-// streams are created with the greatest priority and kept in a pool of their own.
+// hardware queues, round-robin, and a copy stream that shares the compute stream's queue has its barrier packets queued behind the
+// kernels enqueued there.  Streams of another PRIORITY get hardware queues of their own, so the copy streams are created with the
+// greatest priority and kept in a pool of their own.  (Built while hunting the read-backs that ran at half speed; the cause turned out
+// to be the driver wiping freed memory -- gf_devcache.h -- and the priority made no measurable difference: kept, it is the safer
+// arrangement.  GF_COPY_STREAM_PLAIN=1: a stream like any other.)
 hipError_t pool_copy_stream(int device, hipStream_t* stream)
 {
     *stream = nullptr;
@@ -1257,12 +1256,11 @@ bool host_range_is_pinned(const void* p, size_t span, void** alias = nullptr)
     return true;
 }
 
-// Rows of device memory into registered host memory by a KERNEL that stores through the host memory's device alias.  Why not the
-// runtime's DMA: hipMemcpyAsync into registered memory runs at 54-57 GB/s from the FIRST large device allocation of a process and at
-// 30 GB/s from any later one (freed and allocated again, or just allocated after a free: tools/vram_realloc_probe.py -- every scan
-// after a process's first was in that state, which is where "the read-backs vary by box and run" came from), while 32 workgroups of
-// this kernel deliver 55-56 GB/s from either (tools/experiments/d2h_kernel_probe.hip; profiles/r04/host_register.txt).  A tile is
-// 256 lanes x 16 elements of one row; few workgroups on purpose: the link is the bound, and the sampler's kernels keep the GPU.
+// Rows of device memory into registered host memory by a KERNEL that stores through the host memory's device alias: 55-56 GB/s from 32
+// workgroups (tools/experiments/d2h_kernel_probe.hip), and unaffected by what halves the runtime's DMA for ~0.6 s after a large hipFree
+// (the driver wiping the freed memory with the DMA engine: tools/vram_realloc_probe4.py, profiles/r04/host_register.txt).  NOT the
+// default (enqueue_d2h_rows): beside other kernels it costs them a dispatch each, and the device cache keeps the wipe from happening.
+// A tile is 256 lanes x 16 elements of one row; few workgroups on purpose: the link is the bound.
 extern "C++" {
 template <typename T>
 __global__ __launch_bounds__(256) void k_d2h_rows(T* __restrict__ dst, size_t dpitch_e, const T* __restrict__ src, size_t spitch_e,
